@@ -1,0 +1,343 @@
+/*
+ * mirt.h — C ABI of the MI355X wavefront path-tracing core (libmirt).
+ *
+ * This is the boundary a host application binds instead of the reference's
+ * wgpu compute dispatch.  Every entry point names the reference interface it
+ * replaces (paths are relative to the reference checkout).  All structs are
+ * plain-old-data with the byte layout of the reference's #[repr(C)] bytemuck
+ * mirrors, so a Rust caller can pass `Vec<T>::as_ptr()` directly.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MirtStatus;
+ *     mirt_last_error() gives the text of the last failure on that context;
+ *   - inputs are copied during the call (the caller may free them at once);
+ *   - outputs are written into caller-allocated host buffers;
+ *   - a context is used by one thread at a time, from any thread;
+ *   - nothing here throws or aborts across the boundary.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum MirtStatus {
+  MIRT_OK = 0,
+  MIRT_ERR_INVALID_ARGUMENT = -1,
+  MIRT_ERR_NO_DEVICE = -2,
+  MIRT_ERR_OUT_OF_MEMORY = -3,
+  MIRT_ERR_HIP = -4,
+  MIRT_ERR_NOT_READY = -5, /* scene or state missing */
+  MIRT_ERR_BAD_SCENE = -6  /* an index in the scene buffers is out of range */
+} MirtStatus;
+
+/* ------------------------------------------------- scene PODs (bind group 0) */
+
+/* shaders/common.slang:29-33, src/mesh.rs:40-46 (GPUVertexData) */
+typedef struct MirtVertex {
+  float position[4];
+  float normal[4];
+  float uv[4];
+} MirtVertex; /* 48 B */
+
+/* shaders/scene.slang:15 (uint4 index), src/mesh.rs:28 (UVec4 face) */
+typedef struct MirtIndex {
+  uint32_t v[4]; /* xyz used, w = 0 */
+} MirtIndex; /* 16 B */
+
+/* shaders/bvh.slang:8-16, src/bvh.rs:200-224 (BVHNodeGPU); `right` is the
+ * skip link of the threaded traversal (src/bvh.rs:217). */
+typedef struct MirtBVHNode {
+  float lb[4];
+  float ub[4];
+  uint32_t left;
+  uint32_t right;
+  uint32_t is_leaf;
+  uint32_t start;
+  uint32_t end;
+  uint32_t pad[3];
+} MirtBVHNode; /* 64 B */
+
+/* shaders/common.slang:171-175, src/mesh.rs:32-38 */
+typedef struct MirtGeometryOffsets {
+  uint32_t vertex;
+  uint32_t index;
+  uint32_t blas_node;
+} MirtGeometryOffsets; /* 12 B */
+
+/* shaders/common.slang:165-169, src/instance.rs:1-7 */
+typedef struct MirtInstance {
+  uint32_t transform;
+  uint32_t geometry;
+  uint32_t material;
+} MirtInstance; /* 12 B */
+
+/* shaders/common.slang:87-91, src/transform.rs:4-10; rotation = Euler xyz rad */
+typedef struct MirtTransform {
+  float scale[4];
+  float rotation[4];
+  float translation[4];
+} MirtTransform; /* 48 B */
+
+/* shaders/common.slang:7-18, src/material.rs:12-25 */
+typedef struct MirtMaterial {
+  uint32_t colour_texture;
+  uint32_t emissive_texture;
+  uint32_t metallic_roughness_texture;
+  uint32_t normal_texture;
+  float colour[4];
+  float emissive[4];
+  float metallic;
+  float roughness;
+  float ior;
+  float transmission;
+} MirtMaterial; /* 64 B */
+
+/* shaders/common.slang:153-160 (std140), src/camera.rs:102-115 (first 64 B) */
+typedef struct MirtCamera {
+  float position[3];
+  uint32_t pad0;
+  float forward[3];
+  uint32_t pad1;
+  float up[3];
+  uint32_t pad2;
+  float dims[2];
+  float focal_length;
+  uint32_t changed;
+} MirtCamera; /* 64 B */
+
+/* shaders/common.slang:146-151, src/pathtracer_state.rs:64-71 */
+typedef struct MirtSampleSource {
+  float screen_pos[2];
+  uint32_t out_pos[2];
+  uint32_t sample_count;
+  uint32_t flags;
+} MirtSampleSource; /* 24 B */
+
+/* Per-material PODs of the per-material ("classic") shading kernels:
+ * src/lambertian.rs, src/metallic.rs, src/dielectric.rs, src/emissive.rs and
+ * shaders/archive/{lambertian,metallic,dielectric,emissive}.slang. */
+typedef struct MirtLambertianData {
+  float albedo[4];
+} MirtLambertianData; /* 16 B */
+typedef struct MirtMetallicData {
+  float albedo[4];
+  float fuzz;
+  uint32_t pad[3];
+} MirtMetallicData; /* 32 B */
+typedef struct MirtDielectricData {
+  float albedo[4];
+  float ir;
+  uint32_t pad[3];
+} MirtDielectricData; /* 32 B */
+typedef struct MirtEmissiveData {
+  float albedo[4];
+} MirtEmissiveData; /* 16 B */
+
+/* Material kind routing of shaders/archive/logic.slang:170-189 (hit.mat). */
+enum {
+  MIRT_MAT_NONE = 0,
+  MIRT_MAT_LAMBERTIAN = 1,
+  MIRT_MAT_METALLIC = 2,
+  MIRT_MAT_DIELECTRIC = 3,
+  MIRT_MAT_EMISSIVE = 4
+};
+
+/* One entry per slot of the `materials` array: which per-material kernel
+ * shades it and which row of that kernel's data table it uses
+ * (archive Instance.material / Instance.material_data,
+ * shaders/archive/tlas.slang:31-36). */
+typedef struct MirtClassicMaterialRef {
+  uint32_t kind;
+  uint32_t data;
+} MirtClassicMaterialRef; /* 8 B */
+
+/* The ten read-only scene buffers in bind-group-0 order
+ * (shaders/scene.slang:10-29; built by src/binder.rs:325-370 and
+ * src/mesh.rs:198-284), plus the optional per-material tables. */
+typedef struct MirtSceneDesc {
+  const MirtInstance *instances;              uint32_t n_instances;       /* binding 0 */
+  const MirtGeometryOffsets *geometry_offsets; uint32_t n_geometries;     /* binding 1 */
+  const MirtVertex *vertices;                 uint32_t n_vertices;        /* binding 2 */
+  const MirtIndex *indices;                   uint32_t n_indices;         /* binding 3 */
+  const MirtBVHNode *blas_nodes;              uint32_t n_blas_nodes;      /* binding 4 */
+  const MirtMaterial *materials;              uint32_t n_materials;       /* binding 5 */
+  const MirtTransform *transforms;            uint32_t n_transforms;      /* binding 6 */
+  const MirtBVHNode *tlas_nodes;              uint32_t n_tlas_nodes;      /* binding 7 */
+  const uint32_t *tlas_to_instances;          uint32_t n_tlas_to_instances; /* binding 8 */
+  const uint32_t *light_sources;              uint32_t n_light_sources;   /* binding 9 (instance ids; [0xFFFFFFFF] = none) */
+  /* classic shading only; may all be NULL/0 when shade_mode == MIRT_SHADE_UBER */
+  const MirtClassicMaterialRef *classic_refs; uint32_t n_classic_refs;    /* one per material */
+  const MirtLambertianData *lambertian;       uint32_t n_lambertian;
+  const MirtMetallicData *metallic;           uint32_t n_metallic;
+  const MirtDielectricData *dielectric;       uint32_t n_dielectric;
+  const MirtEmissiveData *emissive;           uint32_t n_emissive;
+} MirtSceneDesc;
+
+/* --------------------------------------------------------------- parameters */
+enum { MIRT_SHADE_UBER = 0, MIRT_SHADE_CLASSIC = 1 };
+enum { MIRT_RNG_PER_SAMPLE = 0 };
+
+/* Every literal of the reference kernels that a configuration changes. */
+typedef struct MirtParams {
+  uint32_t max_bounces;   /* shaders/sample.slang:71 (128); archive/logic.slang:119 (8) */
+  float sky_radiance;     /* shaders/ray_extend.slang:36 (10.0) */
+  float fixed_point_scale;/* shaders/sample.slang:45-47 (1000.0); archive 1024.0 */
+  float exposure;         /* shaders/sample.slang:54, exp2(-2.5) */
+  uint32_t shade_mode;    /* MIRT_SHADE_* */
+  uint32_t rng_mode;      /* MIRT_RNG_* */
+  uint32_t seed;          /* RNG stream seed (keyed with source and sample number) */
+  uint32_t nee;           /* classic mode: 1 = trace connect (shadow) rays */
+} MirtParams;
+
+/* --------------------------------------------------------------- ray-set API */
+typedef struct MirtRay {
+  float pos[3];
+  float dir[3];
+  uint32_t last_inst; /* 0x7FFFFFFF = none (shaders/sample.slang:83-84) */
+  uint32_t last_prim;
+} MirtRay; /* 32 B */
+
+typedef struct MirtHitId {
+  uint32_t instance_id; /* 0xFFFFFFFF on a miss */
+  uint32_t triangle_id; /* BLAS-local index after the BVH build's reorder */
+  float t;              /* world-space parameter (FLT_MAX on a miss) */
+  uint32_t front_face;
+} MirtHitId; /* 16 B */
+
+/* Traversal work done for a ray set, in the units of the algorithmic-byte
+ * model (64 B per node visit, 76 B per instance visit, 160 B per triangle). */
+typedef struct MirtTraversalCounts {
+  uint64_t rays;
+  uint64_t tlas_nodes;
+  uint64_t instance_visits;
+  uint64_t blas_nodes;
+  uint64_t triangles;
+} MirtTraversalCounts;
+
+typedef struct MirtStats {
+  uint64_t extend_rays;    /* successful pops of the extension queue */
+  uint64_t connect_rays;   /* successful pops of the connect queue */
+  uint64_t shade_events;
+  uint64_t spawned_samples;
+  uint64_t finished_samples;
+  uint64_t frames;
+  /* per-kernel launch counts and summed HIP-event durations (ms) */
+  uint64_t extend_launches;   double extend_ms;
+  uint64_t connect_launches;  double connect_ms;
+  uint64_t shade_launches;    double shade_ms;
+  uint64_t sample_launches;   double sample_ms;
+  MirtTraversalCounts extend_counts;  /* filled only when counting is enabled */
+  MirtTraversalCounts connect_counts;
+} MirtStats;
+
+typedef struct mirt_ctx mirt_ctx;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+/* Replaces the Vulkan device/queue set-up of src/render_resources.rs:37-116. */
+int mirt_create(int device_ordinal, mirt_ctx **out_ctx);
+int mirt_destroy(mirt_ctx *ctx);
+const char *mirt_last_error(const mirt_ctx *ctx);
+const char *mirt_status_string(int status);
+void mirt_default_params(MirtParams *out);
+
+/* Replaces the buffer creation + bind group 0 of src/binder.rs:292-370 and
+ * src/mesh.rs:198-284.  Validates every index, then lays the scene out in
+ * HBM in the traversal layout. */
+int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *scene);
+
+/* Replaces PathtracerState::new (src/pathtracer_state.rs:96-353) and
+ * PathtracerOutput::new (src/pathtracer.rs:56-122): allocates `threads` path
+ * slots, the four queues, the accumulators for `n_sources` sample sources and
+ * the width*height packed-RGB output. */
+int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height,
+                      uint32_t threads, const MirtSampleSource *sources,
+                      uint32_t n_sources, const MirtParams *params);
+
+/* Replaces Camera::update (src/camera.rs:193-199).  `changed != 0` resets the
+ * accumulators like sampleCleanup (shaders/sample.slang:123-145). */
+int mirt_camera_set(mirt_ctx *ctx, const MirtCamera *camera);
+
+/* Zero sums and counts and restart sample numbering (sampleCleanup). */
+int mirt_reset_accum(mirt_ctx *ctx);
+
+/* Restrict rendering to samples [first_sample, first_sample + n) of every
+ * source (multi-GPU partition of samples-per-pixel). */
+int mirt_set_sample_range(mirt_ctx *ctx, uint32_t first_sample);
+
+/* ---------------------------------------------------------------- rendering */
+
+/* Replaces pathtracer_phase_execute (src/pathtracer_manager.rs:74-124): run
+ * `n_frames` wavefront frames (sample -> extend -> [connect] -> shade), each
+ * advancing every in-flight path by one bounce; samples keep regenerating.
+ * Returns before the work completes. */
+int mirt_step(mirt_ctx *ctx, uint32_t n_frames);
+
+/* Render exactly `spp` further samples for every source and drain the
+ * wavefront (offline form of the same loop).  Synchronises. */
+int mirt_render_spp(mirt_ctx *ctx, uint32_t spp);
+
+int mirt_synchronize(mirt_ctx *ctx);
+
+/* Replaces the buffer->texture copy of src/pathtracer.rs:124-146: tone-map
+ * the means and return width*height packed pixels (R | G<<8 | B<<16). */
+int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels);
+
+/* Raw accumulators: sum4[4*n] (x,y,z fixed-point, w unused) and count[n],
+ * indexed by sample source. */
+int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count,
+                    size_t n_sources);
+
+/* Copy the accumulators into caller-owned DEVICE buffers (for an RCCL
+ * reduction driven by the caller) and load reduced values back. */
+int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count,
+                              size_t n_sources);
+int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4,
+                                const void *dev_count, size_t n_sources);
+
+/* ------------------------------------------------------------ ray-set entry */
+
+/* Closest hit of each ray with the traversal of extensionMain
+ * (shaders/ray_extend.slang:19-215).  `counts` may be NULL. */
+int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
+                       MirtHitId *out, MirtTraversalCounts *counts);
+
+/* Any hit with t in [0, tmax[i]] (shadow / connect query, the role
+ * shaders/ray_connect.slang:1-7 describes).  out[i] is the FIRST triangle the
+ * threaded traversal accepts (instance_id 0xFFFFFFFF when unoccluded). */
+int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax,
+                   size_t n, MirtHitId *out, MirtTraversalCounts *counts);
+
+/* Time `repeats` launches of the closest-hit kernel on a resident ray set
+ * (HIP events on the context's stream); returns the mean ms per launch. */
+int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
+                             uint32_t repeats, double *ms_per_launch);
+
+/* -------------------------------------------------------------- diagnostics */
+int mirt_stats(mirt_ctx *ctx, MirtStats *out);
+int mirt_stats_reset(mirt_ctx *ctx);
+/* 1 = count node/instance/triangle visits inside the render kernels (slower). */
+int mirt_set_counting(mirt_ctx *ctx, int enabled);
+/* 1 = bracket every kernel launch with HIP events (needed for *_ms). */
+int mirt_set_event_timing(mirt_ctx *ctx, int enabled);
+
+/* Dump the per-slot extension rays that the next extend launch would trace
+ * (for building bounce-k ray sets in tests).  Returns the number written. */
+int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity,
+                             size_t *n_written);
+
+/* Elementary arithmetic self-test: evaluates +,-,*,/,sqrt,fma on the device
+ * for caller-provided operands (bit-parity check of the arithmetic contract). */
+int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b,
+                       const float *c, size_t n, float *out6 /* 6*n */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

@@ -1,0 +1,88 @@
+/*
+ * mirt_host.h — C ABI of the host scene model (libmirt_host).
+ *
+ * The reference's host data model is Rust (MeshServer, MaterialServer,
+ * Transform/Instance entities, BLAS/TLAS builders, binder, scenes, camera).
+ * This library restates it in C++ so that scenes can be built where no Rust
+ * toolchain exists; it produces the flat buffers of MirtSceneDesc that
+ * mirt_scene_upload() consumes.  It contains no GPU code and never calls
+ * libmirt.
+ */
+#ifndef MIRT_HOST_H
+#define MIRT_HOST_H
+
+#include "mirt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mirth_scene mirth_scene;
+
+mirth_scene *mirth_scene_new(void);
+void mirth_scene_free(mirth_scene *s);
+const char *mirth_last_error(const mirth_scene *s);
+
+/* MeshServer::load_mesh (src/mesh.rs:149-165).  Each returns a mesh id >= 0
+ * or a negative value on failure.  Meshes are de-duplicated by descriptor. */
+int mirth_load_mesh_obj(mirth_scene *s, const char *path);   /* MeshDescriptor::TOBJ */
+int mirth_load_mesh_rect(mirth_scene *s);                     /* MeshDescriptor::Rect */
+int mirth_load_mesh_cube(mirth_scene *s);                     /* MeshDescriptor::Cube */
+/* A parsed model (what tobj hands to Mesh::from_model, src/mesh.rs:308):
+ * positions/normals are 3 floats each, indices 3 per triangle. */
+int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positions,
+                          uint32_t n_positions, const float *normals, uint32_t n_normals,
+                          const uint32_t *indices, uint32_t n_indices);
+/* Binary dump of a parsed model ("MIRTMESH" file), see mirth_obj_to_model_file. */
+int mirth_load_mesh_model_file(mirth_scene *s, const char *path);
+/* Procedural dragon-class mesh: 2*n_u*n_v triangles. */
+int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed);
+
+/* MaterialServer::add_material (src/material.rs:54-57) */
+int mirth_add_material(mirth_scene *s, const MirtMaterial *m);
+void mirth_default_material(MirtMaterial *out); /* src/material.rs:27-42 */
+void mirth_default_camera(MirtCamera *out);     /* src/camera.rs:117-128 */
+
+/* commands.spawn((Transform, MaterialId, MeshId)) */
+int mirth_spawn(mirth_scene *s, const MirtTransform *t, int mesh_id, int material_id);
+/* spawn_cornell (src/scenes.rs:20-134) */
+int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3], int with_ceiling_light);
+
+/* One of the five benchmark configurations (1..5).  `asset_dir` is searched
+ * for <name>.obj then <name>.mirtmesh for suzanne / teapot / dragon; a missing
+ * dragon falls back to the procedural knot.  Writes the image size, samples
+ * per pixel, bounce limit, shade mode and whether the dragon was procedural. */
+typedef struct MirthConfigInfo {
+  uint32_t width, height, spp, max_bounces, shade_mode, nee;
+  uint32_t procedural_dragon;
+  uint32_t seed;
+} MirthConfigInfo;
+int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32_t dragon_n_u,
+                       uint32_t dragon_n_v, MirthConfigInfo *info);
+
+/* regenerate_buffer + binder_system: pack the flat buffers. */
+int mirth_bind(mirth_scene *s);
+/* Pointers stay valid until the next mirth_bind / mirth_scene_free. */
+int mirth_scene_desc(const mirth_scene *s, MirtSceneDesc *out);
+
+/* Sample sources for a width x height image (src/pathtracer_state.rs:175-195),
+ * seeded; shuffle 2 = reference order (tiles and sources shuffled), 1 = tiles
+ * only, 0 = none.  `out` has width*height entries. */
+int mirth_make_sample_sources(uint32_t width, uint32_t height, uint64_t seed, int shuffle,
+                              MirtSampleSource *out);
+
+/* Parse an OBJ and write the parsed first model as a MIRTMESH file. */
+int mirth_obj_to_model_file(const char *obj_path, const char *out_path);
+
+/* Stand-alone pieces for tests: parse OBJ text; build a BLAS for a mesh id. */
+int mirth_parse_obj_counts(const char *text, size_t len, uint32_t *n_positions, uint32_t *n_normals,
+                           uint32_t *n_triangles);
+int mirth_mesh_counts(const mirth_scene *s, int mesh_id, uint32_t *n_vertices, uint32_t *n_faces,
+                      uint32_t *n_nodes);
+int mirth_mesh_copy(const mirth_scene *s, int mesh_id, float *positions4, float *normals4,
+                    uint32_t *faces4, MirtBVHNode *nodes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_HOST_H */

@@ -1,0 +1,152 @@
+"""ctypes face of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Product code (raytracer_amd/) never imports it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from raytracer_amd import ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("extend_rays", C.c_uint64), ("connect_rays", C.c_uint64), ("shade_events", C.c_uint64),
+                ("finished_samples", C.c_uint64), ("extend_counts", ffi.TraversalCounts),
+                ("connect_counts", ffi.TraversalCounts)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make oracle`")
+        L = C.CDLL(path)
+        vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+        L.oracle_scene_create.restype = vp
+        L.oracle_scene_create.argtypes = [C.POINTER(ffi.SceneDesc)]
+        L.oracle_scene_free.argtypes = [vp]
+        L.oracle_rng_next.restype = C.c_float
+        L.oracle_rng_next.argtypes = [vp]
+        L.oracle_rng_init.argtypes = [u32, u32, u32, vp]
+        L.oracle_trace_closest.argtypes = [vp, vp, sz, vp, C.POINTER(ffi.TraversalCounts)]
+        L.oracle_trace_any.argtypes = [vp, vp, vp, sz, vp, C.POINTER(ffi.TraversalCounts)]
+        L.oracle_trace_brute.argtypes = [vp, vp, sz, vp]
+        L.oracle_render.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp, vp,
+                                    C.POINTER(RenderStats), C.c_int]
+        L.oracle_render_wavefront.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, u32,
+                                              vp, vp, C.POINTER(RenderStats), C.POINTER(C.c_uint64)]
+        L.oracle_bounce_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp]
+        L.oracle_resolve.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), vp]
+        L.oracle_math_selftest.argtypes = [vp, vp, vp, sz, vp]
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    """The reference's literals (MirtParams); keyword arguments override."""
+    p = ffi.Params(max_bounces=128, sky_radiance=10.0, fixed_point_scale=1000.0,
+                   exposure=float(np.exp2(np.float32(-2.5))), shade_mode=0, rng_mode=0, seed=0x5EED0000, nee=0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def rng_sequence(state, n):
+    """n draws from random.slang's generator; returns (values, final state)."""
+    st = np.array(state, dtype="<u4")
+    vals = np.zeros(n, "<f4")
+    for i in range(n):
+        vals[i] = lib().oracle_rng_next(st.ctypes.data)
+    return vals, st
+
+
+def rng_init(seed, source, sample_no):
+    st = np.zeros(4, "<u4")
+    lib().oracle_rng_init(seed, source, sample_no, st.ctypes.data)
+    return st
+
+
+class Scene:
+    def __init__(self, arrays):
+        self.arrays = arrays  # keep alive
+        d = ffi.desc_from_arrays(arrays)
+        self._h = lib().oracle_scene_create(C.byref(d))
+        if not self._h:
+            raise ValueError("oracle_scene_create rejected the scene buffers")
+
+    def close(self):
+        if self._h:
+            lib().oracle_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace_closest(self, rays, want_counts=False):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        out = np.zeros(len(rays), ffi.HitId)
+        c = ffi.TraversalCounts()
+        lib().oracle_trace_closest(self._h, rays.ctypes.data, len(rays), out.ctypes.data, C.byref(c))
+        return (out, c) if want_counts else out
+
+    def trace_any(self, rays, tmax, want_counts=False):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        tmax = np.ascontiguousarray(tmax, "<f4")
+        out = np.zeros(len(rays), ffi.HitId)
+        c = ffi.TraversalCounts()
+        lib().oracle_trace_any(self._h, rays.ctypes.data, tmax.ctypes.data, len(rays), out.ctypes.data, C.byref(c))
+        return (out, c) if want_counts else out
+
+    def trace_brute(self, rays):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        out = np.zeros(len(rays), ffi.HitId)
+        lib().oracle_trace_brute(self._h, rays.ctypes.data, len(rays), out.ctypes.data)
+        return out
+
+    def render(self, camera, sources, width, height, params, first_sample, spp, threads=0, sum4=None, count=None):
+        n = len(sources)
+        sum4 = np.zeros(4 * n, "<u4") if sum4 is None else sum4
+        count = np.zeros(n, "<u4") if count is None else count
+        st = RenderStats()
+        lib().oracle_render(self._h, camera.ctypes.data, sources.ctypes.data, n, width, height, C.byref(params),
+                            first_sample, spp, sum4.ctypes.data, count.ctypes.data, C.byref(st), threads)
+        return sum4, count, st
+
+    def render_wavefront(self, camera, sources, width, height, params, first_sample, spp, slots):
+        n = len(sources)
+        sum4 = np.zeros(4 * n, "<u4")
+        count = np.zeros(n, "<u4")
+        st = RenderStats()
+        frames = C.c_uint64()
+        lib().oracle_render_wavefront(self._h, camera.ctypes.data, sources.ctypes.data, n, width, height,
+                                      C.byref(params), first_sample, spp, slots, sum4.ctypes.data,
+                                      count.ctypes.data, C.byref(st), C.byref(frames))
+        return sum4, count, st, frames.value
+
+    def bounce_rays(self, camera, sources, width, height, params, sample_no, bounce):
+        out = np.zeros(len(sources), ffi.Ray)
+        lib().oracle_bounce_rays(self._h, camera.ctypes.data, sources.ctypes.data, len(sources), width, height,
+                                 C.byref(params), sample_no, bounce, out.ctypes.data)
+        return out
+
+
+def resolve(sum4, count, sources, width, height, params):
+    rgb = np.zeros(width * height, "<u4")
+    lib().oracle_resolve(sum4.ctypes.data, count.ctypes.data, sources.ctypes.data, len(sources), width, height,
+                         C.byref(params), rgb.ctypes.data)
+    return rgb
+
+
+def math_selftest(a, b, c):
+    out = np.zeros(6 * len(a), "<f4")
+    lib().oracle_math_selftest(a.ctypes.data, b.ctypes.data, c.ctypes.data, len(a), out.ctypes.data)
+    return out

@@ -1,0 +1,953 @@
+// api.hip — the extern "C" boundary of libmirt (include/mirt.h): context,
+// scene upload into the traversal layout, path-state allocation, the frame
+// loop, read-back and the ray-set entry points.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "mirt.h"
+
+using namespace mirt;
+
+namespace {
+
+struct EventPair {
+  hipEvent_t a, b;
+  int kind;
+};
+
+enum KernelKind { K_SAMPLE = 0, K_EXTEND, K_CONNECT, K_SHADE, K_KINDS };
+
+}  // namespace
+
+struct mirt_ctx {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // scene
+  bool have_scene = false;
+  DScene sc{};
+  std::vector<void *> scene_allocs;
+  uint32_t n_instances = 0;
+
+  // state
+  bool have_state = false;
+  DState st{};
+  std::vector<void *> state_allocs;
+  MirtParams params{};
+  MirtCamera camera{};
+  bool have_camera = false;
+  uint32_t next_sample = 0;  // sample number the next render call starts at
+  uint32_t frame = 0;
+  bool slots_seeded = false;
+
+  // diagnostics
+  bool counting = false;
+  bool event_timing = false;
+  std::vector<EventPair> ev_free, ev_pending;
+  double kernel_ms[K_KINDS] = {0, 0, 0, 0};
+  uint64_t kernel_launches[K_KINDS] = {0, 0, 0, 0};
+  uint64_t frames_total = 0;
+  unsigned long long *h_stats = nullptr;  // pinned, S_COUNT + Q_COUNT words
+  unsigned long long *d_trace_counts = nullptr;
+};
+
+namespace {
+
+int fail(mirt_ctx *c, int status, const std::string &msg) {
+  if (c) c->error = msg;
+  return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return fail(ctx, _e == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_HIP,       \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                           \
+  } while (0)
+
+template <typename T>
+int dev_alloc(mirt_ctx *c, std::vector<void *> &owner, T **out, size_t count) {
+  void *p = nullptr;
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(c, hipMalloc(&p, bytes));
+  owner.push_back(p);
+  *out = reinterpret_cast<T *>(p);
+  return MIRT_OK;
+}
+
+template <typename T>
+int dev_upload(mirt_ctx *c, std::vector<void *> &owner, const T **out, const std::vector<T> &host) {
+  T *p = nullptr;
+  int rc = dev_alloc(c, owner, &p, host.size());
+  if (rc != MIRT_OK) return rc;
+  if (!host.empty()) HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = p;
+  return MIRT_OK;
+}
+
+void free_all(std::vector<void *> &v) {
+  for (void *p : v) (void)hipFree(p);
+  v.clear();
+}
+
+// ---- instance matrices: Transform.matrix() / matrix_inverse()
+// (shaders/common.slang:41-111) evaluated once per instance on the host with
+// the shader's own order of 4x4 products, instead of per ray x instance visit.
+void mat4_mul(const float a[4][4], const float b[4][4], float o[4][4]) {
+  float t[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = a[i][0] * b[0][j];
+      acc = acc + a[i][1] * b[1][j];
+      acc = acc + a[i][2] * b[2][j];
+      acc = acc + a[i][3] * b[3][j];
+      t[i][j] = acc;
+    }
+  memcpy(o, t, sizeof(t));
+}
+void mat4_identity(float m[4][4]) {
+  memset(m, 0, 64);
+  m[0][0] = m[1][1] = m[2][2] = m[3][3] = 1.0f;
+}
+void instance_matrices(const MirtTransform &t, float M[12], float Mi[12]) {
+  float S[4][4], R[4][4], T[4][4], rx[4][4], ry[4][4], rz[4][4], tmp[4][4], m[4][4];
+  const float x = t.rotation[0], y = t.rotation[1], z = t.rotation[2];
+  mat4_identity(rx); mat4_identity(ry); mat4_identity(rz);
+  rx[1][1] = cosf(x); rx[1][2] = -sinf(x); rx[2][1] = sinf(x); rx[2][2] = cosf(x);
+  ry[0][0] = cosf(y); ry[0][2] = sinf(y); ry[2][0] = -sinf(y); ry[2][2] = cosf(y);
+  rz[0][0] = cosf(z); rz[0][1] = -sinf(z); rz[1][0] = sinf(z); rz[1][1] = cosf(z);
+  mat4_mul(ry, rz, tmp);
+  mat4_mul(rx, tmp, R);
+  mat4_identity(S); S[0][0] = t.scale[0]; S[1][1] = t.scale[1]; S[2][2] = t.scale[2];
+  mat4_identity(T); T[0][3] = t.translation[0]; T[1][3] = t.translation[1]; T[2][3] = t.translation[2];
+  mat4_mul(R, S, tmp);
+  mat4_mul(T, tmp, m);
+  memcpy(M, m, 48);
+  float Si[4][4], Rt[4][4], Ti[4][4], mi[4][4];
+  mat4_identity(Si);
+  Si[0][0] = 1.0f / t.scale[0]; Si[1][1] = 1.0f / t.scale[1]; Si[2][2] = 1.0f / t.scale[2];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Rt[i][j] = R[j][i];
+  mat4_identity(Ti); Ti[0][3] = -t.translation[0]; Ti[1][3] = -t.translation[1]; Ti[2][3] = -t.translation[2];
+  mat4_mul(Rt, Ti, tmp);
+  mat4_mul(Si, tmp, mi);
+  memcpy(Mi, mi, 48);
+}
+
+// The threaded walk moves from a node to its left child or to its skip link
+// and ends when it arrives back at node 0.  It ends for every pattern of box
+// hits iff the graph of those two kinds of edges, with the edges into node 0
+// removed, has no cycle reachable from node 0.
+bool walk_terminates(const MirtBVHNode *nodes, uint32_t n) {
+  std::vector<uint8_t> colour(n, 0);  // 0 new, 1 on the DFS stack, 2 done
+  std::vector<std::pair<uint32_t, uint8_t>> stack;
+  stack.push_back({0u, 0});
+  colour[0] = 1;
+  while (!stack.empty()) {
+    auto &[node, next_edge] = stack.back();
+    const MirtBVHNode &nd = nodes[node];
+    uint32_t target = 0;
+    bool have = false;
+    while (next_edge < 2 && !have) {
+      if (next_edge == 0) { if (nd.is_leaf == 0) { target = nd.left; have = true; } }
+      else { target = nd.right; have = true; }
+      ++next_edge;
+    }
+    if (!have) {
+      colour[node] = 2;
+      stack.pop_back();
+      continue;
+    }
+    if (target == 0u) continue;  // the walk ends there
+    if (colour[target] == 1) return false;
+    if (colour[target] == 0) {
+      colour[target] = 1;
+      stack.push_back({target, 0});
+    }
+  }
+  return true;
+}
+
+// Every index a kernel will follow is checked here, once, so that no launch
+// can read outside its buffers or walk forever.
+bool validate_scene(const MirtSceneDesc *d, std::string &why) {
+  auto bad = [&](const char *m) { why = m; return false; };
+  if (!d->instances || !d->n_instances) return bad("no instances");
+  if (!d->geometry_offsets || !d->n_geometries || !d->vertices || !d->indices || !d->blas_nodes)
+    return bad("missing geometry buffers");
+  if (!d->materials || !d->n_materials || !d->transforms || !d->n_transforms) return bad("missing materials/transforms");
+  if (!d->tlas_nodes || !d->n_tlas_nodes || !d->tlas_to_instances) return bad("missing TLAS buffers");
+  if (d->n_tlas_nodes > kMaxNodesPerTree) return bad("TLAS has more than 2^24 nodes");
+  for (uint32_t i = 0; i < d->n_instances; ++i)
+    if (d->instances[i].transform >= d->n_transforms || d->instances[i].geometry >= d->n_geometries ||
+        d->instances[i].material >= d->n_materials)
+      return bad("instance refers to a missing transform, geometry or material");
+  for (uint32_t i = 0; i < d->n_tlas_to_instances; ++i)
+    if (d->tlas_to_instances[i] >= d->n_instances) return bad("tlas_to_instances entry out of range");
+  for (uint32_t i = 0; i < d->n_tlas_nodes; ++i) {
+    const MirtBVHNode &n = d->tlas_nodes[i];
+    if (n.right >= d->n_tlas_nodes) return bad("TLAS skip link out of range");
+    if (n.is_leaf > 1) return bad("TLAS is_leaf must be 0 or 1");
+    if (n.is_leaf) {
+      if (n.start >= n.end || n.end > d->n_tlas_to_instances) return bad("TLAS leaf empty or out of range");
+    } else if (n.left >= d->n_tlas_nodes || n.left == 0) {
+      return bad("TLAS child link out of range");
+    }
+  }
+  if (!walk_terminates(d->tlas_nodes, d->n_tlas_nodes)) return bad("TLAS links form a cycle");
+  for (uint32_t g = 0; g < d->n_geometries; ++g) {
+    const MirtGeometryOffsets &o = d->geometry_offsets[g];
+    const bool last = g + 1 == d->n_geometries;
+    const uint32_t node_end = last ? d->n_blas_nodes : d->geometry_offsets[g + 1].blas_node;
+    const uint32_t idx_end = last ? d->n_indices : d->geometry_offsets[g + 1].index;
+    const uint32_t vtx_end = last ? d->n_vertices : d->geometry_offsets[g + 1].vertex;
+    if (o.blas_node >= node_end || node_end > d->n_blas_nodes || o.index > idx_end || idx_end > d->n_indices ||
+        o.vertex > vtx_end || vtx_end > d->n_vertices)
+      return bad("geometry offsets are not ascending or exceed the buffers");
+    const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index, nv = vtx_end - o.vertex;
+    if (nn > kMaxNodesPerTree) return bad("a BLAS has more than 2^24 nodes");
+    for (uint32_t i = 0; i < nn; ++i) {
+      const MirtBVHNode &n = d->blas_nodes[o.blas_node + i];
+      if (n.right >= nn) return bad("BLAS skip link out of range");
+      if (n.is_leaf > 1) return bad("BLAS is_leaf must be 0 or 1");
+      if (n.is_leaf) {
+        if (n.start >= n.end || n.end > ni) return bad("BLAS leaf empty or out of range");
+      } else if (n.left >= nn || n.left == 0) {
+        return bad("BLAS child link out of range");
+      }
+    }
+    if (!walk_terminates(d->blas_nodes + o.blas_node, nn)) return bad("BLAS links form a cycle");
+    for (uint32_t i = 0; i < ni; ++i)
+      for (int k = 0; k < 3; ++k)
+        if (d->indices[o.index + i].v[k] >= nv) return bad("vertex index out of range");
+  }
+  const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
+  if (!no_lights)
+    for (uint32_t i = 0; i < d->n_light_sources; ++i)
+      if (d->light_sources[i] >= d->n_instances) return bad("light source instance out of range");
+  if (d->n_classic_refs) {
+    if (d->n_classic_refs != d->n_materials || !d->classic_refs) return bad("classic_refs must have one entry per material");
+    for (uint32_t i = 0; i < d->n_classic_refs; ++i) {
+      const MirtClassicMaterialRef r = d->classic_refs[i];
+      uint32_t lim = 0;
+      switch (r.kind) {
+        case MIRT_MAT_NONE: continue;
+        case MIRT_MAT_LAMBERTIAN: lim = d->lambertian ? d->n_lambertian : 0; break;
+        case MIRT_MAT_METALLIC: lim = d->metallic ? d->n_metallic : 0; break;
+        case MIRT_MAT_DIELECTRIC: lim = d->dielectric ? d->n_dielectric : 0; break;
+        case MIRT_MAT_EMISSIVE: lim = d->emissive ? d->n_emissive : 0; break;
+        default: return bad("unknown classic material kind");
+      }
+      if (r.data >= lim) return bad("classic material row out of range");
+    }
+  }
+  return true;
+}
+
+// Pack one tree's reference nodes into DNodes.  `sizes_out` receives the
+// out-of-line size of every node (only read for leaves marked kBigLeaf).
+void pack_nodes(const MirtBVHNode *src, uint32_t n, DNode *dst, uint32_t *sizes_out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const MirtBVHNode &s = src[i];
+    DNode d;
+    d.lbx = s.lb[0]; d.lby = s.lb[1]; d.lbz = s.lb[2];
+    d.ubx = s.ub[0]; d.uby = s.ub[1]; d.ubz = s.ub[2];
+    // is_leaf == 1 marks a leaf exactly like the kernels' `node.is_leaf == 1`
+    // test; any other value walks on as an inner node.
+    if (s.is_leaf == 1) {
+      const uint32_t cnt = s.end - s.start;  // >= 1, checked by validate_scene
+      const uint32_t tag = cnt < kBigLeaf ? cnt : kBigLeaf;
+      d.a = s.start;
+      d.b = (s.right & kSkipMask) | (tag << 24);
+      if (sizes_out) sizes_out[i] = cnt;
+    } else {
+      d.a = s.left;
+      d.b = (s.right & kSkipMask);
+      if (sizes_out) sizes_out[i] = 0;
+    }
+    dst[i] = d;
+  }
+}
+
+int get_ctx_device(mirt_ctx *c) {
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, MIRT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return MIRT_OK;
+}
+
+#define ENTER(ctx)                                   \
+  if (!(ctx)) return MIRT_ERR_INVALID_ARGUMENT;      \
+  {                                                  \
+    int _rc = get_ctx_device(ctx);                   \
+    if (_rc != MIRT_OK) return _rc;                  \
+  }
+
+LaunchCfg launch_cfg(mirt_ctx *c) {
+  LaunchCfg cfg;
+  cfg.stream = c->stream;
+  uint32_t want = c->have_state ? (c->st.slots + 255u) / 256u : 1u;
+  uint32_t cap = (uint32_t)c->num_cus * 8u;
+  cfg.grid_blocks = (int)(want < cap ? (want ? want : 1u) : cap);
+  return cfg;
+}
+
+DFrameParams frame_params(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample) {
+  DFrameParams fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.p = c->params;
+  fp.cam = c->camera;
+  fp.sample_limit = sample_limit;
+  fp.first_sample = first_sample;
+  fp.frame = c->frame;
+  fp.have_lights = c->sc.n_lights > 0 ? 1u : 0u;
+  fp.counting = c->counting ? 1u : 0u;
+  return fp;
+}
+
+// --- optional per-kernel timing with HIP events on the context's stream
+void ev_begin(mirt_ctx *c, int kind, EventPair &ep) {
+  if (c->ev_free.empty()) {
+    EventPair n;
+    (void)hipEventCreate(&n.a);
+    (void)hipEventCreate(&n.b);
+    c->ev_free.push_back(n);
+  }
+  ep = c->ev_free.back();
+  c->ev_free.pop_back();
+  ep.kind = kind;
+  (void)hipEventRecord(ep.a, c->stream);
+}
+void ev_end(mirt_ctx *c, EventPair &ep) {
+  (void)hipEventRecord(ep.b, c->stream);
+  c->ev_pending.push_back(ep);
+}
+void ev_collect(mirt_ctx *c) {  // call after a stream synchronisation
+  for (EventPair &ep : c->ev_pending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) c->kernel_ms[ep.kind] += (double)ms;
+    c->ev_free.push_back(ep);
+  }
+  c->ev_pending.clear();
+}
+
+template <typename F>
+void timed_launch(mirt_ctx *c, int kind, F &&f) {
+  c->kernel_launches[kind]++;
+  if (c->event_timing) {
+    EventPair ep;
+    ev_begin(c, kind, ep);
+    f();
+    ev_end(c, ep);
+  } else {
+    f();
+  }
+}
+
+int seed_slots(mirt_ctx *c) {
+  launch_init_slots(launch_cfg(c), c->st);
+  HIP_TRY(c, hipMemsetAsync(c->st.sample_index, 0, sizeof(unsigned long long), c->stream));
+  c->frame = 0;
+  c->slots_seeded = true;
+  return MIRT_OK;
+}
+
+void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample) {
+  const LaunchCfg cfg = launch_cfg(c);
+  const DFrameParams fp = frame_params(c, sample_limit, first_sample);
+  timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
+  timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
+  if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
+    if (c->params.nee && fp.have_lights) timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
+    timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
+  } else {
+    timed_launch(c, K_SHADE, [&] { launch_shade_uber(cfg, c->sc, c->st, fp); });
+  }
+  c->frame++;
+  c->frames_total++;
+}
+
+// Read the device counters (stats then queue counts) into pinned memory.
+int fetch_counters(mirt_ctx *c) {
+  HIP_TRY(c, hipMemcpyAsync(c->h_stats, c->st.stats, S_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_stats + S_COUNT, c->st.qcount, Q_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  ev_collect(c);
+  return MIRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mirt_status_string(int status) {
+  switch (status) {
+    case MIRT_OK: return "ok";
+    case MIRT_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MIRT_ERR_NO_DEVICE: return "no HIP device";
+    case MIRT_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case MIRT_ERR_HIP: return "HIP runtime error";
+    case MIRT_ERR_NOT_READY: return "scene, state or camera not set";
+    case MIRT_ERR_BAD_SCENE: return "scene buffers are inconsistent";
+    default: return "unknown status";
+  }
+}
+
+const char *mirt_last_error(const mirt_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+void mirt_default_params(MirtParams *out) {
+  if (!out) return;
+  out->max_bounces = 128;          // shaders/sample.slang:71
+  out->sky_radiance = 10.0f;       // shaders/ray_extend.slang:36
+  out->fixed_point_scale = 1000.0f;// shaders/sample.slang:45-47
+  out->exposure = 0.17677669529663687f;  // exp2(-2.5), shaders/sample.slang:54
+  out->shade_mode = MIRT_SHADE_UBER;
+  out->rng_mode = MIRT_RNG_PER_SAMPLE;
+  out->seed = 0x5EED0000u;
+  out->nee = 0;
+}
+
+int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
+  if (!out_ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIRT_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= n) return MIRT_ERR_INVALID_ARGUMENT;
+  mirt_ctx *c = new (std::nothrow) mirt_ctx();
+  if (!c) return MIRT_ERR_OUT_OF_MEMORY;
+  c->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess) { delete c; return MIRT_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MIRT_ERR_HIP; }
+  if (hipHostMalloc((void **)&c->h_stats, (S_COUNT + Q_COUNT) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&c->d_trace_counts, 5 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MIRT_ERR_OUT_OF_MEMORY;
+  }
+  mirt_default_params(&c->params);
+  *out_ctx = c;
+  return MIRT_OK;
+}
+
+int mirt_destroy(mirt_ctx *ctx) {
+  if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  free_all(ctx->scene_allocs);
+  free_all(ctx->state_allocs);
+  for (EventPair &ep : ctx->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  for (EventPair &ep : ctx->ev_pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+  if (ctx->d_trace_counts) (void)hipFree(ctx->d_trace_counts);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MIRT_OK;
+}
+
+int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
+  ENTER(ctx);
+  if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+  std::string why;
+  if (!validate_scene(d, why)) return fail(ctx, MIRT_ERR_BAD_SCENE, why);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->scene_allocs);
+  ctx->have_scene = false;
+  DScene sc{};
+
+  // TLAS nodes: node i at element i+1 of a 64-B aligned array, so that the
+  // child pair (l, l+1), l odd, shares a 64-B line.
+  {
+    std::vector<DNode> nodes(d->n_tlas_nodes + 1);
+    std::vector<uint32_t> big(d->n_tlas_nodes);
+    memset(&nodes[0], 0, sizeof(DNode));
+    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, nodes.data() + 1, big.data());
+    const DNode *p = nullptr;
+    int rc = dev_upload(ctx, ctx->scene_allocs, &p, nodes);
+    if (rc != MIRT_OK) return rc;
+    sc.tlas = p + 1;
+    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_big, big);
+    if (rc != MIRT_OK) return rc;
+    std::vector<uint32_t> t2i(d->tlas_to_instances, d->tlas_to_instances + d->n_tlas_to_instances);
+    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_to_inst, t2i);
+    if (rc != MIRT_OK) return rc;
+  }
+
+  // BLAS nodes and triangles, one block per geometry.
+  std::vector<uint32_t> geom_node_base(d->n_geometries), geom_tri_base(d->n_geometries);
+  {
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris(d->n_indices);
+    std::vector<DTriN> trins(d->n_indices);
+    nodes.reserve((size_t)d->n_blas_nodes + 2 * d->n_geometries + 1);
+    nodes.push_back(DNode{});  // element 0 unused: every block starts at an odd element
+    for (uint32_t g = 0; g < d->n_geometries; ++g) {
+      const MirtGeometryOffsets &o = d->geometry_offsets[g];
+      const bool last = g + 1 == d->n_geometries;
+      const uint32_t node_end = last ? d->n_blas_nodes : d->geometry_offsets[g + 1].blas_node;
+      const uint32_t idx_end = last ? d->n_indices : d->geometry_offsets[g + 1].index;
+      const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index;
+      if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
+      geom_node_base[g] = (uint32_t)nodes.size();
+      geom_tri_base[g] = o.index;
+      const size_t at = nodes.size();
+      nodes.resize(at + nn);
+      std::vector<uint32_t> sizes(nn);
+      pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data());
+      for (uint32_t p = 0; p < ni; ++p) {
+        const MirtIndex &f = d->indices[o.index + p];
+        const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
+        const MirtVertex &v1 = d->vertices[o.vertex + f.v[1]];
+        const MirtVertex &v2 = d->vertices[o.vertex + f.v[2]];
+        DTri t;
+        memset(&t, 0, sizeof(t));
+        t.p0x = v0.position[0]; t.p0y = v0.position[1]; t.p0z = v0.position[2];
+        t.e1x = v1.position[0] - v0.position[0]; t.e1y = v1.position[1] - v0.position[1]; t.e1z = v1.position[2] - v0.position[2];
+        t.e2x = v2.position[0] - v0.position[0]; t.e2y = v2.position[1] - v0.position[1]; t.e2z = v2.position[2] - v0.position[2];
+        tris[o.index + p] = t;
+        DTriN n;
+        memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
+        trins[o.index + p] = n;
+      }
+      // out-of-line leaf sizes ride in the first triangle of the leaf
+      for (uint32_t i = 0; i < nn; ++i) {
+        const DNode &dn = nodes[at + i];
+        if ((dn.b >> 24) == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
+      }
+    }
+    if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
+    const DNode *pn = nullptr;
+    int rc = dev_upload(ctx, ctx->scene_allocs, &pn, nodes);
+    if (rc != MIRT_OK) return rc;
+    sc.blas = pn;
+    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tri, tris);
+    if (rc != MIRT_OK) return rc;
+    rc = dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
+    if (rc != MIRT_OK) return rc;
+  }
+
+  // instances
+  {
+    std::vector<DInst> insts(d->n_instances);
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+      const MirtInstance &in = d->instances[i];
+      DInst di;
+      memset(&di, 0, sizeof(di));
+      instance_matrices(d->transforms[in.transform], di.m, di.mi);
+      di.node_base = geom_node_base[in.geometry];
+      di.tri_base = geom_tri_base[in.geometry];
+      di.material = in.material;
+      if (d->n_classic_refs) {
+        di.kind = d->classic_refs[in.material].kind;
+        di.kind_data = d->classic_refs[in.material].data;
+      }
+      const MirtBVHNode &root = d->blas_nodes[d->geometry_offsets[in.geometry].blas_node];
+      // light sampling draws from the primitive range of the BLAS root
+      // (archive/light.slang:60-64); for an inner root that is all triangles
+      di.root_start = root.start;
+      di.root_count = root.end - root.start;
+      insts[i] = di;
+    }
+    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.inst, insts);
+    if (rc != MIRT_OK) return rc;
+  }
+
+  // materials and per-material tables
+  {
+    std::vector<DMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+      DMaterial m;
+      memset(&m, 0, sizeof(m));
+      memcpy(m.colour, d->materials[i].colour, 16);
+      memcpy(m.emissive, d->materials[i].emissive, 16);
+      m.metallic = d->materials[i].metallic;
+      m.roughness = d->materials[i].roughness;
+      m.ior = d->materials[i].ior;
+      m.transmission = d->materials[i].transmission;
+      mats[i] = m;
+    }
+    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.mat, mats);
+    if (rc != MIRT_OK) return rc;
+    const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
+    std::vector<uint32_t> lights;
+    if (!no_lights) lights.assign(d->light_sources, d->light_sources + d->n_light_sources);
+    sc.n_lights = (uint32_t)lights.size();
+    rc = dev_upload(ctx, ctx->scene_allocs, &sc.lights, lights);
+    if (rc != MIRT_OK) return rc;
+    std::vector<float> lam, met, die, emi;
+    if (d->n_classic_refs) {
+      if (d->lambertian) lam.assign((const float *)d->lambertian, (const float *)d->lambertian + 4 * (size_t)d->n_lambertian);
+      if (d->metallic) met.assign((const float *)d->metallic, (const float *)d->metallic + 8 * (size_t)d->n_metallic);
+      if (d->dielectric) die.assign((const float *)d->dielectric, (const float *)d->dielectric + 8 * (size_t)d->n_dielectric);
+      if (d->emissive) emi.assign((const float *)d->emissive, (const float *)d->emissive + 4 * (size_t)d->n_emissive);
+    }
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.lambertian, lam)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.metallic, met)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.dielectric, die)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.emissive, emi)) != MIRT_OK) return rc;
+  }
+
+  ctx->sc = sc;
+  ctx->n_instances = d->n_instances;
+  ctx->have_scene = true;
+  return MIRT_OK;
+}
+
+int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t threads,
+                      const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) {
+  ENTER(ctx);
+  if (!width || !height || !threads || !sources || !n_sources || !params)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: zero size or null pointer");
+  if (params->max_bounces == 0 || params->shade_mode > MIRT_SHADE_CLASSIC || params->rng_mode != MIRT_RNG_PER_SAMPLE)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: bad params");
+  if (!(params->fixed_point_scale > 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: fixed_point_scale must be > 0");
+  for (uint32_t i = 0; i < n_sources; ++i)
+    if (sources[i].out_pos[0] >= width || sources[i].out_pos[1] >= height)
+      return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: sample source outside the image");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->state_allocs);
+  ctx->have_state = false;
+  DState st{};
+  st.slots = threads;
+  st.n_sources = n_sources;
+  st.width = width;
+  st.height = height;
+  int rc;
+  auto &own = ctx->state_allocs;
+  if ((rc = dev_alloc(ctx, own, &st.ray, threads)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.hit, threads)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.path, threads)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.shadow, threads)) != MIRT_OK) return rc;
+  for (int q = 0; q < Q_COUNT; ++q)
+    if ((rc = dev_alloc(ctx, own, &st.qdata[q], threads)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.qcount, Q_COUNT)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.stats, S_COUNT)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.sample_index, 1)) != MIRT_OK) return rc;
+  MirtSampleSource *dsrc = nullptr;
+  if ((rc = dev_alloc(ctx, own, &dsrc, n_sources)) != MIRT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpy(dsrc, sources, (size_t)n_sources * sizeof(MirtSampleSource), hipMemcpyHostToDevice));
+  st.sources = dsrc;
+  if ((rc = dev_alloc(ctx, own, &st.sum4, (size_t)4 * n_sources)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.count, n_sources)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.output, (size_t)width * height)) != MIRT_OK) return rc;
+  HIP_TRY(ctx, hipMemset(st.sum4, 0, (size_t)16 * n_sources));
+  HIP_TRY(ctx, hipMemset(st.count, 0, (size_t)4 * n_sources));
+  HIP_TRY(ctx, hipMemset(st.output, 0, (size_t)4 * width * height));
+  HIP_TRY(ctx, hipMemset(st.stats, 0, S_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemset(st.qcount, 0, Q_COUNT * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemset(st.sample_index, 0, sizeof(unsigned long long)));
+  ctx->st = st;
+  ctx->params = *params;
+  ctx->have_state = true;
+  ctx->next_sample = 0;
+  ctx->frame = 0;
+  ctx->slots_seeded = false;
+  return MIRT_OK;
+}
+
+int mirt_camera_set(mirt_ctx *ctx, const MirtCamera *camera) {
+  ENTER(ctx);
+  if (!camera) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera is null");
+  ctx->camera = *camera;
+  ctx->have_camera = true;
+  if (camera->changed != 0 && ctx->have_state) return mirt_reset_accum(ctx);
+  return MIRT_OK;
+}
+
+int mirt_reset_accum(mirt_ctx *ctx) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  // sampleCleanup (shaders/sample.slang:123-145) for every source, including
+  // the tail its integer work split leaves out.  Counts restart at 0, not 1.
+  HIP_TRY(ctx, hipMemsetAsync(ctx->st.sum4, 0, (size_t)16 * ctx->st.n_sources, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->st.count, 0, (size_t)4 * ctx->st.n_sources, ctx->stream));
+  ctx->next_sample = 0;
+  ctx->slots_seeded = false;  // in-flight paths are dropped
+  return MIRT_OK;
+}
+
+int mirt_set_sample_range(mirt_ctx *ctx, uint32_t first_sample) {
+  ENTER(ctx);
+  ctx->next_sample = first_sample;
+  ctx->slots_seeded = false;
+  return MIRT_OK;
+}
+
+static int check_ready(mirt_ctx *ctx) {
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state created");
+  if (!ctx->have_camera) return fail(ctx, MIRT_ERR_NOT_READY, "no camera set");
+  if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && ctx->sc.lambertian == nullptr)
+    return fail(ctx, MIRT_ERR_NOT_READY, "classic shading needs the per-material tables");
+  return MIRT_OK;
+}
+
+int mirt_step(mirt_ctx *ctx, uint32_t n_frames) {
+  ENTER(ctx);
+  int rc = check_ready(ctx);
+  if (rc != MIRT_OK) return rc;
+  if (!ctx->slots_seeded && (rc = seed_slots(ctx)) != MIRT_OK) return rc;
+  // samples keep regenerating: no limit on the number handed out
+  for (uint32_t f = 0; f < n_frames; ++f) run_frame(ctx, ~0ull, ctx->next_sample);
+  return MIRT_OK;
+}
+
+int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
+  ENTER(ctx);
+  int rc = check_ready(ctx);
+  if (rc != MIRT_OK) return rc;
+  if (spp == 0) return MIRT_OK;
+  if ((rc = seed_slots(ctx)) != MIRT_OK) return rc;  // drops paths left by mirt_step
+  const unsigned long long limit = (unsigned long long)ctx->st.n_sources * spp;
+  const uint32_t first = ctx->next_sample;
+  if ((rc = fetch_counters(ctx)) != MIRT_OK) return rc;
+  const unsigned long long finished0 = ctx->h_stats[S_FINISHED];
+  // Each frame advances every path by one bounce.  Poll the finished-sample
+  // counter every few frames; the loop ends when all samples of this call
+  // have been accumulated.
+  const uint32_t poll = 4;
+  while (true) {
+    for (uint32_t f = 0; f < poll; ++f) run_frame(ctx, limit, first);
+    if ((rc = fetch_counters(ctx)) != MIRT_OK) return rc;
+    if (ctx->h_stats[S_FINISHED] - finished0 >= limit) break;
+  }
+  ctx->next_sample = first + spp;
+  ctx->slots_seeded = false;
+  return MIRT_OK;
+}
+
+int mirt_synchronize(mirt_ctx *ctx) {
+  ENTER(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ev_collect(ctx);
+  return MIRT_OK;
+}
+
+int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (!rgb || n_pixels != (size_t)ctx->st.width * ctx->st.height)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_output: n_pixels must be width*height");
+  launch_resolve(launch_cfg(ctx), ctx->st, frame_params(ctx, 0, 0));
+  HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->st.output, n_pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ev_collect(ctx);
+  return MIRT_OK;
+}
+
+int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_accum: n_sources mismatch");
+  if (sum4) HIP_TRY(ctx, hipMemcpyAsync(sum4, ctx->st.sum4, n_sources * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (count) HIP_TRY(ctx, hipMemcpyAsync(count, ctx->st.count, n_sources * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ev_collect(ctx);
+  return MIRT_OK;
+}
+
+int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "copy_accum: n_sources mismatch");
+  if (dev_sum4) HIP_TRY(ctx, hipMemcpyAsync(dev_sum4, ctx->st.sum4, n_sources * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(dev_count, ctx->st.count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4, const void *dev_count, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "load_accum: n_sources mismatch");
+  if (dev_sum4) HIP_TRY(ctx, hipMemcpyAsync(ctx->st.sum4, dev_sum4, n_sources * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(ctx->st.count, dev_count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, size_t n, MirtHitId *out,
+                        MirtTraversalCounts *counts, bool any_hit, uint32_t repeats, double *ms_per_launch) {
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  if (n == 0) return MIRT_OK;
+  if (!rays || (!out && !ms_per_launch) || (any_hit && !tmax)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: null pointer");
+  if (n > 0xFFFFFFFFull) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: more than 2^32-1 rays");
+  for (size_t i = 0; i < n; ++i)
+    if (rays[i].last_inst != 0x7FFFFFFFu && rays[i].last_inst >= ctx->n_instances && rays[i].last_inst != 0xFFFFFFFFu)
+      return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: last_inst out of range");
+  std::vector<void *> tmp;
+  DRay *d_rays = nullptr;
+  float *d_tmax = nullptr;
+  MirtHitId *d_out = nullptr;
+  int rc;
+  if ((rc = dev_alloc(ctx, tmp, &d_rays, n)) != MIRT_OK) { free_all(tmp); return rc; }
+  if ((rc = dev_alloc(ctx, tmp, &d_out, n)) != MIRT_OK) { free_all(tmp); return rc; }
+  if (any_hit && (rc = dev_alloc(ctx, tmp, &d_tmax, n)) != MIRT_OK) { free_all(tmp); return rc; }
+  hipError_t e = hipMemcpy(d_rays, rays, n * sizeof(MirtRay), hipMemcpyHostToDevice);
+  if (e == hipSuccess && any_hit) e = hipMemcpy(d_tmax, tmax, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_trace_counts, 0, 5 * sizeof(unsigned long long), ctx->stream);
+  if (e != hipSuccess) { free_all(tmp); return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e)); }
+  LaunchCfg cfg;
+  cfg.stream = ctx->stream;
+  cfg.grid_blocks = ctx->num_cus * 8;
+  if (ms_per_launch) {
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, false);  // warm-up
+    (void)hipEventRecord(a, ctx->stream);
+    for (uint32_t r = 0; r < repeats; ++r) launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, false);
+    (void)hipEventRecord(b, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    *ms_per_launch = repeats ? (double)ms / repeats : 0.0;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  } else {
+    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, counts != nullptr);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess && out) e = hipMemcpy(out, d_out, n * sizeof(MirtHitId), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && counts) {
+    unsigned long long h[5];
+    e = hipMemcpy(h, ctx->d_trace_counts, sizeof(h), hipMemcpyDeviceToHost);
+    counts->rays = h[0]; counts->tlas_nodes = h[1]; counts->instance_visits = h[2];
+    counts->blas_nodes = h[3]; counts->triangles = h[4];
+  }
+  free_all(tmp);
+  if (e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e));
+  return MIRT_OK;
+}
+
+int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out, MirtTraversalCounts *counts) {
+  ENTER(ctx);
+  return trace_common(ctx, rays, nullptr, n, out, counts, false, 0, nullptr);
+}
+
+int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, size_t n, MirtHitId *out,
+                   MirtTraversalCounts *counts) {
+  ENTER(ctx);
+  return trace_common(ctx, rays, tmax, n, out, counts, true, 0, nullptr);
+}
+
+int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, uint32_t repeats, double *ms_per_launch) {
+  ENTER(ctx);
+  if (!ms_per_launch || repeats == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bench_trace: bad arguments");
+  return trace_common(ctx, rays, nullptr, n, nullptr, nullptr, false, repeats, ms_per_launch);
+}
+
+int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
+  ENTER(ctx);
+  if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "stats: null pointer");
+  memset(out, 0, sizeof(*out));
+  if (ctx->have_state) {
+    int rc = fetch_counters(ctx);
+    if (rc != MIRT_OK) return rc;
+    const unsigned long long *s = ctx->h_stats;
+    out->extend_rays = s[S_EXTEND_RAYS];
+    out->connect_rays = s[S_CONNECT_RAYS];
+    out->shade_events = s[S_SHADE_EVENTS];
+    out->spawned_samples = s[S_SPAWNED];
+    out->finished_samples = s[S_FINISHED];
+    out->extend_counts.rays = s[S_EXTEND_RAYS];
+    out->extend_counts.tlas_nodes = s[S_EXT_TLAS];
+    out->extend_counts.instance_visits = s[S_EXT_INST];
+    out->extend_counts.blas_nodes = s[S_EXT_BLAS];
+    out->extend_counts.triangles = s[S_EXT_TRI];
+    out->connect_counts.rays = s[S_CONNECT_RAYS];
+    out->connect_counts.tlas_nodes = s[S_CON_TLAS];
+    out->connect_counts.instance_visits = s[S_CON_INST];
+    out->connect_counts.blas_nodes = s[S_CON_BLAS];
+    out->connect_counts.triangles = s[S_CON_TRI];
+  }
+  out->frames = ctx->frames_total;
+  out->extend_launches = ctx->kernel_launches[K_EXTEND];   out->extend_ms = ctx->kernel_ms[K_EXTEND];
+  out->connect_launches = ctx->kernel_launches[K_CONNECT]; out->connect_ms = ctx->kernel_ms[K_CONNECT];
+  out->shade_launches = ctx->kernel_launches[K_SHADE];     out->shade_ms = ctx->kernel_ms[K_SHADE];
+  out->sample_launches = ctx->kernel_launches[K_SAMPLE];   out->sample_ms = ctx->kernel_ms[K_SAMPLE];
+  return MIRT_OK;
+}
+
+int mirt_stats_reset(mirt_ctx *ctx) {
+  ENTER(ctx);
+  if (ctx->have_state) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ev_collect(ctx);
+    HIP_TRY(ctx, hipMemset(ctx->st.stats, 0, S_COUNT * sizeof(unsigned long long)));
+  }
+  for (int k = 0; k < K_KINDS; ++k) { ctx->kernel_ms[k] = 0.0; ctx->kernel_launches[k] = 0; }
+  ctx->frames_total = 0;
+  return MIRT_OK;
+}
+
+int mirt_set_counting(mirt_ctx *ctx, int enabled) {
+  ENTER(ctx);
+  ctx->counting = enabled != 0;
+  return MIRT_OK;
+}
+
+int mirt_set_event_timing(mirt_ctx *ctx, int enabled) {
+  ENTER(ctx);
+  ctx->event_timing = enabled != 0;
+  return MIRT_OK;
+}
+
+int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_t *n_written) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (!out || !n_written) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "dump: null pointer");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the next extend launch pops the extension queue of the current parity
+  // after the sample kernel has topped it up; what is there now are the
+  // bounce rays pushed by the last shade launch
+  const uint32_t par = ctx->frame & 1u;
+  uint32_t cnt = 0;
+  HIP_TRY(ctx, hipMemcpy(&cnt, ctx->st.qcount + Q_EXT0 + par, 4, hipMemcpyDeviceToHost));
+  if (cnt > ctx->st.slots) return fail(ctx, MIRT_ERR_HIP, "dump: queue count exceeds slots");
+  std::vector<uint32_t> idx(cnt);
+  if (cnt) HIP_TRY(ctx, hipMemcpy(idx.data(), ctx->st.qdata[Q_EXT0 + par], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  std::vector<MirtRay> all(ctx->st.slots);
+  HIP_TRY(ctx, hipMemcpy(all.data(), ctx->st.ray, (size_t)ctx->st.slots * sizeof(MirtRay), hipMemcpyDeviceToHost));
+  size_t w = 0;
+  for (uint32_t k = 0; k < cnt && w < capacity; ++k) out[w++] = all[idx[k]];
+  *n_written = w;
+  return MIRT_OK;
+}
+
+int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const float *c, size_t n, float *out6) {
+  ENTER(ctx);
+  if (!a || !b || !c || !out6) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "selftest: null pointer");
+  if (n == 0) return MIRT_OK;
+  std::vector<void *> tmp;
+  float *da = nullptr, *db = nullptr, *dc = nullptr, *dout = nullptr;
+  int rc;
+  if ((rc = dev_alloc(ctx, tmp, &da, n)) != MIRT_OK || (rc = dev_alloc(ctx, tmp, &db, n)) != MIRT_OK ||
+      (rc = dev_alloc(ctx, tmp, &dc, n)) != MIRT_OK || (rc = dev_alloc(ctx, tmp, &dout, 6 * n)) != MIRT_OK) {
+    free_all(tmp);
+    return rc;
+  }
+  hipError_t e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dc, c, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_math_selftest(ctx->stream, da, db, dc, n, dout);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(out6, dout, 6 * n * 4, hipMemcpyDeviceToHost);
+  free_all(tmp);
+  if (e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e));
+  return MIRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// kernels.h — launch interface between the C ABI (api.hip) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+#include "mirt.h"
+
+namespace mirt {
+
+// Queue ids.  The terminate and extension queues are double-buffered by frame
+// parity: a queue is popped in one kernel and its counter is cleared by a
+// later kernel that neither pops nor pushes it, so no kernel ever pushes and
+// pops the same queue (the reference keeps that invariant too).
+enum QueueId {
+  Q_TERM0 = 0, Q_TERM1, Q_EXT0, Q_EXT1, Q_SHADE, Q_CONNECT, Q_LAMBERTIAN, Q_METALLIC, Q_DIELECTRIC, Q_EMISSIVE,
+  Q_COUNT
+};
+
+// Device counters kept beside the queue counters.
+enum StatId {
+  S_EXTEND_RAYS = 0, S_CONNECT_RAYS, S_SHADE_EVENTS, S_SPAWNED, S_FINISHED,
+  S_EXT_TLAS, S_EXT_INST, S_EXT_BLAS, S_EXT_TRI, S_CON_TLAS, S_CON_INST, S_CON_BLAS, S_CON_TRI,
+  S_COUNT
+};
+
+struct DState {
+  DRay *ray;            // [slots]
+  DHit *hit;            // [slots]
+  DPath *path;          // [slots]
+  DShadow *shadow;      // [slots] (classic shading)
+  uint32_t *qdata[Q_COUNT];  // [slots] each
+  uint32_t *qcount;     // [Q_COUNT]
+  unsigned long long *stats;         // [S_COUNT]
+  unsigned long long *sample_index;  // next sample to hand out in this render call
+  const MirtSampleSource *sources;   // [n_sources]
+  uint32_t *sum4;       // [4 * n_sources]
+  uint32_t *count;      // [n_sources]
+  uint32_t *output;     // [width * height]
+  uint32_t slots, n_sources, width, height;
+};
+
+struct DFrameParams {
+  MirtParams p;
+  MirtCamera cam;
+  unsigned long long sample_limit;  // samples to hand out in this render call
+  uint32_t first_sample;            // sample number of sample_index 0
+  uint32_t frame;                   // frame parity selects the queue buffers
+  uint32_t have_lights;
+  uint32_t counting;
+};
+
+struct LaunchCfg {
+  hipStream_t stream;
+  int grid_blocks;  // blocks of 256 threads for the frame kernels
+};
+
+void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
+void launch_init_slots(const LaunchCfg &cfg, const DState &st);
+
+void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,
+                  MirtHitId *out, unsigned long long *counts5, bool any_hit, bool counting);
+void launch_math_selftest(hipStream_t stream, const float *a, const float *b, const float *c, size_t n, float *out6);
+
+}  // namespace mirt

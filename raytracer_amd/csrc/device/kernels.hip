@@ -1,0 +1,504 @@
+// kernels.hip — the wavefront kernels: sample (accumulate + new_ray), extend,
+// shade, and the ray-set trace kernels, for gfx950 (wave64).
+//
+// One frame advances every in-flight path by one bounce:
+//   sample  pops the terminate queue: accumulates the finished sample
+//           (shaders/sample.slang:35-57) and spawns the next camera ray into
+//           the same slot (sample.slang:59-102)                -> extension queue
+//   extend  pops the extension queue: closest hit
+//           (shaders/ray_extend.slang:19-51)                   -> shade | terminate
+//   shade   pops the shade queue: material evaluation and the next bounce
+//           (shaders/shade.slang:154-224)                      -> extension | terminate
+//
+// Queues are index lists.  Popping needs no atomics: entry i of a queue goes to
+// global thread i (grid-stride), because no kernel pushes the queue it pops.
+// Pushing compacts with wave64 ballots: a wave counts its pushing lanes with
+// one ballot, ranks them with mbcnt, and reserves its slice of the tail with a
+// single atomic; the cheap uniform kernels first combine their four waves'
+// counts in LDS so that a 256-thread block issues one atomic per queue.
+#include <float.h>
+
+#include "kernels.h"
+#include "device_util.h"
+
+namespace mirt {
+
+namespace {
+
+// ---------------------------------------------------------------- sample
+
+// accumulateSample (shaders/sample.slang:35-47).  uint() of a negative or huge
+// float is undefined in the reference; this clamps to [0, 2^32).
+__device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
+  if (__builtin_isnan(rad) || __builtin_isinf(rad)) rad = 0.0f;
+  const float x = rad * scale;
+  if (!(x >= 0.0f)) return 0u;
+  if (x >= 4294967040.0f) return 4294967040u;
+  return (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *term = st.qdata[Q_TERM0 + par];
+  uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_TERM0 + par];
+  const MirtCamera &cam = fp.cam;
+
+  // camera basis (shaders/sample.slang:87-90)
+  const v3 fwd = V3(cam.forward[0], cam.forward[1], cam.forward[2]);
+  const v3 up = V3(cam.up[0], cam.up[1], cam.up[2]);
+  const v3 right = cross3(fwd, up);
+  const float dx = cam.dims[0], dy = cam.dims[1];
+  const v3 top_left = sub3(add3(scale3(fwd, cam.focal_length), scale3(up, dy)), scale3(right, dx));
+
+  unsigned long long finished = 0, spawned = 0;
+  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < count;
+    uint32_t slot = 0;
+    DPath *pp = nullptr;
+    if (active) {
+      slot = term[i];
+      pp = st.path + slot;
+      const float4 a = reinterpret_cast<const float4 *>(pp)[0];
+      const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
+      if (source != kNoSample) {
+        atomicAdd(&st.count[source], 1u);
+        atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(a.x, fp.p.fixed_point_scale));
+        atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(a.y, fp.p.fixed_point_scale));
+        atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(a.z, fp.p.fixed_point_scale));
+        finished++;
+      }
+    }
+    // pull the next sample (shaders/sample.slang:64-68): one atomic per wave
+    const unsigned long long mask = __ballot(active);
+    unsigned long long si = ~0ull;
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      unsigned long long b = 0;
+      if ((int)lane_id() == leader) b = atomicAdd(st.sample_index, (unsigned long long)__popcll(mask));
+      b = __shfl(b, leader);
+      si = b + rank_in_mask(mask);
+    }
+    const bool spawn = active && si < fp.sample_limit;
+    if (spawn) {
+      uint32_t source, k;
+      if ((si >> 32) == 0ull) {
+        source = (uint32_t)si % st.n_sources;
+        k = (uint32_t)si / st.n_sources;
+      } else {
+        source = (uint32_t)(si % st.n_sources);
+        k = (uint32_t)(si / st.n_sources);
+      }
+      k += fp.first_sample;
+      const MirtSampleSource src = st.sources[source];
+      Rng rng = rng_init(fp.p.seed, source, k);
+      const float r1 = rng_next(rng);  // x jitter takes the first draw
+      const float r2 = rng_next(rng);
+      const float jx = r1 / (float)st.width, jy = r2 / (float)st.height;
+      const float sy = src.screen_pos[1] + jy, sx = src.screen_pos[0] + jx;
+      const v3 offset = add3(scale3(scale3(scale3(up, -2.0f), dy), sy), scale3(scale3(scale3(right, 2.0f), dx), sx));
+      const v3 dir = normalize3(add3(top_left, offset));
+      float4 *p4 = reinterpret_cast<float4 *>(pp);
+      p4[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(fp.p.max_bounces));
+      p4[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(source));
+      p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+      store_ray(st.ray, slot, V3(cam.position[0], cam.position[1], cam.position[2]), dir, kNoPrim, kNoPrim);
+      spawned++;
+    } else if (active) {
+      reinterpret_cast<uint32_t *>(pp)[7] = kNoSample;  // the slot retires
+    }
+    block_push2(sh, &st.qcount[Q_EXT0 + par], ext, spawn, nullptr, nullptr, false, slot);
+  }
+  // per-wave totals -> stats
+  for (int off = 32; off > 0; off >>= 1) {
+    finished += __shfl_down(finished, off);
+    spawned += __shfl_down(spawned, off);
+  }
+  if (lane_id() == 0u) {
+    if (finished) atomicAdd(&st.stats[S_FINISHED], finished);
+    if (spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // clear the counters of the queues that are idle during this kernel
+    st.qcount[Q_TERM0 + (par ^ 1u)] = 0u;
+    st.qcount[Q_EXT0 + (par ^ 1u)] = 0u;
+    st.qcount[Q_SHADE] = 0u;
+    st.qcount[Q_CONNECT] = 0u;
+    st.qcount[Q_LAMBERTIAN] = 0u;
+    st.qcount[Q_METALLIC] = 0u;
+    st.qcount[Q_DIELECTRIC] = 0u;
+    st.qcount[Q_EMISSIVE] = 0u;
+  }
+}
+
+// Every slot starts on the terminate queue holding no sample, so the first
+// frame only spawns.  (The reference starts with a full terminate queue of
+// zeroed samples, which credits `slots` bogus samples to source 0:
+// src/queue.rs:14-18, shaders/sample.slang:38.)
+__global__ __launch_bounds__(256) void k_init_slots(DState st) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < st.slots) {
+    st.qdata[Q_TERM0][i] = i;
+    reinterpret_cast<uint32_t *>(st.path + i)[7] = kNoSample;
+  }
+  if (i < Q_COUNT) st.qcount[i] = i == Q_TERM0 ? st.slots : 0u;
+}
+
+// ---------------------------------------------------------------- extend
+
+template <bool CLASSIC, bool COUNT>
+__global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFrameParams fp) {
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_EXT0 + par];
+  uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
+  uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t n_waves = gridDim.x * 4u;
+  LaneCounts lc;
+
+  for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+    const uint32_t i = base + lane_id();
+    const bool active = i < count;
+    uint32_t slot = 0;
+    bool hit = false;
+    uint32_t route = 0;  // classic: queue of the hit material
+    if (active) {
+      slot = ext[i];
+      v3 pos, dir;
+      uint32_t last_inst, last_prim;
+      load_ray(st.ray, slot, pos, dir, last_inst, last_prim);
+      float t = FLT_MAX;
+      BestHit best;
+      hit = traverse<false, COUNT>(sc, pos, dir, last_inst, last_prim, t, best, lc);
+      DPath *pp = st.path + slot;
+      if (!hit) {
+        // shaders/ray_extend.slang:34-38: rad += throughput * sky
+        float4 *p4 = reinterpret_cast<float4 *>(pp);
+        float4 a = p4[0];
+        const float4 b = p4[1];
+        const float sky = fp.p.sky_radiance;
+        a.x = a.x + b.x * sky;
+        a.y = a.y + b.y * sky;
+        a.z = a.z + b.z * sky;
+        p4[0] = a;
+      } else {
+        v3 hp, hn;
+        uint32_t ff;
+        finish_hit(sc, dir, best, hp, hn, ff);
+        float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+        h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
+        h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
+        if (CLASSIC) {
+          // archive/extension.slang:94-101: a hit costs one bounce; out of
+          // bounces means terminate without shading
+          uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
+          const uint32_t bounces = *pb - 1u;
+          *pb = bounces;
+          if (bounces == 0u) {
+            hit = false;
+          } else if (fp.p.nee && fp.have_lights) {
+            route = Q_CONNECT;
+          } else {
+            route = Q_LAMBERTIAN - 1u + sc.inst[best.inst].kind;
+            if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
+          }
+        }
+      }
+    }
+    wave_push(term_cnt, term, active && !hit, slot);
+    if (!CLASSIC) {
+      wave_push(&st.qcount[Q_SHADE], st.qdata[Q_SHADE], hit, slot);
+    } else {
+      wave_push(&st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], hit && route == Q_CONNECT, slot);
+      wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], hit && route == Q_LAMBERTIAN, slot);
+      wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], hit && route == Q_METALLIC, slot);
+      wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
+      wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
+    }
+  }
+  if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
+}
+
+// ------------------------------------------------------------ shade (uber)
+
+// unitDiskSample (shaders/shade.slang:101-109)
+__device__ __forceinline__ void unit_disk_sample(Rng &rng, float &x, float &y) {
+  float px, py;
+  do {
+    px = 2.0f * rng_next(rng) - 1.0f;
+    py = 2.0f * rng_next(rng) - 1.0f;
+  } while (__builtin_sqrtf(__builtin_fmaf(py, py, px * px)) > 1.0f);
+  x = px;
+  y = py;
+}
+// unitSphereSample (shaders/shade.slang:115-124): only its draw count is
+// observable, its value feeds dead code in shadeMain.
+__device__ __forceinline__ void unit_sphere_sample_draws(Rng &rng) {
+  v3 p;
+  do {
+    const float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng);
+    p = V3(r1, r2, r3);
+  } while (length3(p) > 1.0f);
+}
+// cosineHemisphereSample (shaders/shade.slang:130-140)
+__device__ __forceinline__ v3 cosine_hemisphere_sample(v3 n, Rng &rng) {
+  float dx, dy;
+  unit_disk_sample(rng, dx, dy);
+  const float z = __builtin_sqrtf(fmax_nn(0.0f, 1.0f - dx * dx - dy * dy));
+  const v3 temp = __builtin_fabsf(n.x) > 0.9f ? V3(0.0f, 1.0f, 0.0f) : V3(1.0f, 0.0f, 0.0f);
+  const v3 t1 = normalize3(cross3(n, temp));
+  const v3 t2 = cross3(n, t1);
+  const v3 nn = normalize3(n);
+  return V3(__builtin_fmaf(nn.x, z, __builtin_fmaf(t2.x, dy, t1.x * dx)),
+            __builtin_fmaf(nn.y, z, __builtin_fmaf(t2.y, dy, t1.y * dx)),
+            __builtin_fmaf(nn.z, z, __builtin_fmaf(t2.z, dy, t1.z * dx)));
+}
+// Only the draws of a cosineHemisphereSample whose value is unused.
+__device__ __forceinline__ void cosine_hemisphere_draws(Rng &rng) {
+  float dx, dy;
+  unit_disk_sample(rng, dx, dy);
+}
+
+__device__ __forceinline__ float heaviside(float x) { return x > 0.0f ? 1.0f : 0.0f; }
+__device__ __forceinline__ v3 mix3(v3 a, v3 b, float m) {  // shaders/shade.slang:24-26
+  const float k = 1.0f - m;
+  return V3(k * a.x + m * b.x, k * a.y + m * b.y, k * a.z + m * b.z);
+}
+// specularBRDF (shaders/shade.slang:40-53)
+__device__ __forceinline__ float specular_brdf(v3 wi, v3 wo, v3 n, float alpha) {
+  const v3 h = normalize3(add3(wo, wi));
+  const float a2 = alpha * alpha;
+  const float nh = dot3(n, h);
+  float d = a2 * heaviside(nh);
+  d /= kPi * pow2f(pow2f(nh) * (a2 - 1.0f) + 1.0f);
+  const float nwi = dot3(n, wi), nwo = dot3(n, wo);
+  const float nwi2 = pow2f(nwi), nwo2 = pow2f(nwo);
+  float v = heaviside(dot3(h, wi)) / (__builtin_fabsf(nwi) + __builtin_sqrtf(a2 + (1.0f - a2) * nwi2));
+  v *= heaviside(dot3(h, wo)) / (__builtin_fabsf(nwo) + __builtin_sqrtf(a2 + (1.0f - a2) * nwo2));
+  return v * d;
+}
+// specularBTDF (shaders/shade.slang:59-72); its three lanes are equal
+__device__ __forceinline__ float specular_btdf(v3 wi, v3 wo, v3 n, float alpha) {
+  const float nwi = dot3(n, wi), nwo = dot3(n, wo);
+  const v3 ht = normalize3(add3(sub3(wo, scale3(n, 2.0f * nwi)), wi));
+  const float a2 = alpha * alpha;
+  const float nht = dot3(n, ht);
+  float dt = a2 * heaviside(nht);
+  dt /= kPi * pow2f(pow2f(nht) * (a2 - 1.0f) + 1.0f);
+  float vt = heaviside(dot3(ht, wi) / nwi);
+  vt *= heaviside(dot3(ht, wo) / nwo);
+  vt /= __builtin_fabsf(nwi) + __builtin_sqrtf(a2 + (1.0f - a2)) * pow2f(nwi);
+  vt /= __builtin_fabsf(nwo) + __builtin_sqrtf(a2 + (1.0f - a2)) * pow2f(nwo);
+  return vt * dt;
+}
+// material() = mix(dielectricBRDF, metallicBRDF, metallic) (shaders/shade.slang:19-99)
+__device__ __forceinline__ v3 material_brdf(v3 wi, v3 wo, v3 n, const DMaterial &m) {
+  const v3 colour = V3(m.colour[0], m.colour[1], m.colour[2]);
+  const float alpha = pow2f(m.roughness);
+  const v3 h = normalize3(add3(wo, wi));
+  const float fres = pow5f(1.0f - __builtin_fabsf(dot3(wo, h)));
+  const float spec = specular_brdf(wi, wo, n, alpha);
+  const v3 diffuse = scale3(colour, 1.0f / kPi);
+  const float btdf = specular_btdf(wi, wo, n, alpha);
+  const v3 base = mix3(diffuse, scale3(colour, btdf), m.transmission);
+  const float f0 = pow2f((1.0f - m.ior) / (1.0f + m.ior));
+  const float fr = f0 + (1.0f - f0) * fres;
+  const v3 dielectric = mix3(base, V3(spec, spec, spec), fr);
+  const v3 metallic = V3(spec * (colour.x + (1.0f - colour.x) * fres), spec * (colour.y + (1.0f - colour.y) * fres),
+                         spec * (colour.z + (1.0f - colour.z) * fres));
+  return mix3(dielectric, metallic, m.metallic);
+}
+
+__global__ __launch_bounds__(256) void k_shade_uber(DScene sc, DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *shq = st.qdata[Q_SHADE];
+  const uint32_t count = st.qcount[Q_SHADE];
+  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < count;
+    uint32_t slot = 0;
+    bool alive = false;
+    if (active) {
+      slot = shq[i];
+      float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+      float4 pa = p4[0], pb = p4[1];
+      const float4 pr = p4[2];
+      Rng rng{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)};
+      v3 rpos, wo;
+      uint32_t li, lp;
+      load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
+      const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+      const float4 ha = h4[0], hb = h4[1];
+      const uint32_t inst_ff = __float_as_uint(ha.w);
+      const uint32_t inst = inst_ff & 0x7FFFFFFFu, ff = inst_ff >> 31, prim = __float_as_uint(hb.w);
+      const DMaterial mat = sc.mat[sc.inst[inst].material];
+
+      // s.rad += s.throughput * mat.emissive.rgb
+      pa.x = pa.x + pb.x * mat.emissive[0];
+      pa.y = pa.y + pb.y * mat.emissive[1];
+      pa.z = pa.z + pb.z * mat.emissive[2];
+      const float sgn = ff != 0u ? 1.0f : -1.0f;
+      const v3 n = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
+
+      cosine_hemisphere_draws(rng);   // diffuse_sample: value unused, draws kept
+      unit_sphere_sample_draws(rng);  // metallicSample -> unitSphereSample
+      const v3 wi = cosine_hemisphere_sample(n, rng);
+      const float pdf = __builtin_fabsf(dot3(wi, n)) / kPi;
+      const v3 brdf = material_brdf(wi, wo, n, mat);
+      const float ndotwi = __builtin_fabsf(dot3(n, wi));
+      pb.x = pb.x * (brdf.x * ndotwi * 1.0f / pdf);
+      pb.y = pb.y * (brdf.y * ndotwi * 1.0f / pdf);
+      pb.z = pb.z * (brdf.z * ndotwi * 1.0f / pdf);
+      const uint32_t bounces = __float_as_uint(pa.w) - 1u;
+      pa.w = __uint_as_float(bounces);
+      alive = bounces != 0u;
+      p4[0] = pa;
+      p4[1] = pb;
+      p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+      // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just
+      // hit is excluded from the next traversal instead
+      store_ray(st.ray, slot, V3(ha.x, ha.y, ha.z), wi, inst, prim);
+    }
+    block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
+                &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)count);
+}
+
+// --------------------------------------------------------------- resolve
+
+__device__ __forceinline__ float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+
+// acesToneMap + packRgb (shaders/sample.slang:18-33,52-56; common.slang:177-183)
+// over the final means.  The reference tone-maps inside accumulateSample with
+// the count from BEFORE its own increment; the final count is used here.
+__global__ __launch_bounds__(256) void k_resolve(DState st, DFrameParams fp) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= st.n_sources) return;
+  const MirtSampleSource src = st.sources[i];
+  const uint32_t ox = src.out_pos[0], oy = src.out_pos[1];
+  if (ox >= st.width || oy >= st.height) return;
+  const uint32_t cnt = st.count[i];
+  const float denom = fp.p.fixed_point_scale * (float)cnt;
+  float rad[3], v[3], c[3], o[3];
+  for (int k = 0; k < 3; ++k) rad[k] = ((float)st.sum4[4 * (size_t)i + k] / denom) * fp.p.exposure;
+  const float m1[3][3] = {{0.59719f, 0.35458f, 0.04823f}, {0.07600f, 0.90834f, 0.01566f}, {0.02840f, 0.13383f, 0.83770f}};
+  const float m2[3][3] = {{1.60475f, -0.53108f, -0.07367f}, {-0.10208f, 1.10813f, -0.00605f}, {-0.00327f, -0.07276f, 1.07602f}};
+  for (int k = 0; k < 3; ++k) v[k] = m1[k][0] * rad[0] + m1[k][1] * rad[1] + m1[k][2] * rad[2];
+  for (int k = 0; k < 3; ++k) {
+    const float a = v[k] * (v[k] + 0.0245786f) - 0.000090537f;
+    const float b = v[k] * (0.983729f * v[k] + 0.4329510f) + 0.238081f;
+    c[k] = a / b;
+  }
+  for (int k = 0; k < 3; ++k) o[k] = saturate(m2[k][0] * c[0] + m2[k][1] * c[1] + m2[k][2] * c[2]);
+  uint32_t r = (uint32_t)(saturate(o[0]) * 255.0f), g = (uint32_t)(saturate(o[1]) * 255.0f),
+           b = (uint32_t)(saturate(o[2]) * 255.0f);
+  if (cnt == 0u) r = g = b = 0u;
+  st.output[(size_t)ox + (size_t)oy * st.width] = (b << 16) | (g << 8) | r;  // .bgr swizzle: red in the low byte
+}
+
+// ----------------------------------------------------------------- trace
+
+template <bool ANY, bool COUNT>
+__global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
+                                               MirtHitId *out, unsigned long long *counts5) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t n_waves = gridDim.x * 4u;
+  LaneCounts lc;
+  for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
+    const uint32_t i = base + lane_id();
+    if (i < n) {
+      v3 pos, dir;
+      uint32_t last_inst, last_prim;
+      load_ray(rays, i, pos, dir, last_inst, last_prim);
+      float t = ANY ? tmax[i] : FLT_MAX;
+      BestHit best;
+      MirtHitId o{0xFFFFFFFFu, 0xFFFFFFFFu, FLT_MAX, 0u};
+      if (traverse<ANY, COUNT>(sc, pos, dir, last_inst, last_prim, t, best, lc)) {
+        o.instance_id = best.inst;
+        o.triangle_id = best.prim;
+        o.t = t;
+        if (!ANY) {
+          v3 hp, hn;
+          uint32_t ff;
+          finish_hit(sc, dir, best, hp, hn, ff);
+          o.front_face = ff;
+        }
+      }
+      reinterpret_cast<float4 *>(out)[i] =
+          make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
+    }
+  }
+  if (COUNT) flush_counts(counts5, 1, lc);
+  if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counts5[0], (unsigned long long)n);
+}
+
+__global__ void k_math_selftest(const float *a, const float *b, const float *c, uint32_t n, float *out6) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out6[6 * i + 0] = a[i] + b[i];
+  out6[6 * i + 1] = a[i] - b[i];
+  out6[6 * i + 2] = a[i] * b[i];
+  out6[6 * i + 3] = a[i] / b[i];
+  out6[6 * i + 4] = __builtin_sqrtf(__builtin_fabsf(a[i]));
+  out6[6 * i + 5] = __builtin_fmaf(a[i], b[i], c[i]);
+}
+
+}  // namespace
+
+// --------------------------------------------------------------- launchers
+
+void launch_init_slots(const LaunchCfg &cfg, const DState &st) {
+  const uint32_t n = st.slots > (uint32_t)Q_COUNT ? st.slots : (uint32_t)Q_COUNT;
+  hipLaunchKernelGGL(k_init_slots, dim3((n + 255u) / 256u), dim3(256), 0, cfg.stream, st);
+}
+
+void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
+  hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, st, fp);
+}
+
+void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  const bool classic = fp.p.shade_mode == MIRT_SHADE_CLASSIC;
+  if (classic) {
+    if (fp.counting) hipLaunchKernelGGL((k_extend<true, true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend<true, false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  } else {
+    if (fp.counting) hipLaunchKernelGGL((k_extend<false, true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend<false, false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  }
+}
+
+void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  hipLaunchKernelGGL(k_shade_uber, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+}
+
+void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {
+  hipLaunchKernelGGL(k_resolve, dim3((st.n_sources + 255u) / 256u), dim3(256), 0, cfg.stream, st, fp);
+}
+
+void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,
+                  MirtHitId *out, unsigned long long *counts5, bool any_hit, bool counting) {
+  if (n == 0) return;
+  size_t want = (n + 255) / 256;
+  const int blocks = (int)(want < (size_t)cfg.grid_blocks ? want : (size_t)cfg.grid_blocks);
+  const uint32_t n32 = (uint32_t)n;
+  if (any_hit) {
+    if (counting) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+  } else {
+    if (counting) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+  }
+}
+
+void launch_math_selftest(hipStream_t stream, const float *a, const float *b, const float *c, size_t n, float *out6) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_math_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, c, (uint32_t)n, out6);
+}
+
+}  // namespace mirt

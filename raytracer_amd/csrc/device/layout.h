@@ -1,0 +1,138 @@
+// layout.h — how the scene and the path state are laid out in HBM.
+//
+// The caller hands over the reference's buffers (64-B nodes, 16-B index rows
+// pointing into 48-B vertices, 48-B Euler transforms).  Traversal is a chain
+// of dependent loads, so the upload re-packs them so that every step is ONE
+// aligned fetch and nothing is recomputed per ray:
+//
+//   DNode (32 B)   box + two words.  Node i of a tree sits at byte offset
+//                  32*(base+i) with base odd, so the two children of a node —
+//                  always pushed as the pair (l, l+1) with l odd by the
+//                  builder — share one 64-B line.
+//   DTri (48 B)    p0, e1 = p1-p0, e2 = p2-p0 of triangle p, indexed by the
+//                  BLAS-local triangle id the leaves refer to: one 48-B fetch
+//                  per test instead of a 16-B index row plus three 48-B
+//                  vertices.  e1/e2 are the same f32 subtractions the kernel
+//                  would do, so results are unchanged.
+//   DTriN (48 B)   the three vertex normals, fetched once for the winning
+//                  triangle only.
+//   DInst (128 B)  world->object and object->world 3x4 matrices (the
+//                  reference rebuilds both with six sin/cos and four 4x4
+//                  products for every ray x instance visit), the node / triangle
+//                  bases and the material of an instance.
+//
+// Topology, box values, visit order and triangle ids are the builder's,
+// untouched: equal-t ties and the set of visited leaves stay identical.
+#pragma once
+
+#include <stdint.h>
+
+namespace mirt {
+
+// word b: bits 0..23 skip link (next node when this subtree is done),
+//         bits 24..31 leaf size: 0 = inner, 1..254 = leaf with that many
+//         primitives, 255 = leaf whose size is stored out of line
+//         (BLAS: bits of DTri[start].p0w; TLAS: tlas_big[node]).
+// word a: inner -> left child; leaf -> first primitive (BLAS-local triangle id
+//         or TLAS slot).
+struct DNode {
+  float lbx, lby, lbz;
+  uint32_t a;
+  float ubx, uby, ubz;
+  uint32_t b;
+};
+static_assert(sizeof(DNode) == 32, "DNode must be 32 bytes");
+
+constexpr uint32_t kSkipMask = 0x00FFFFFFu;
+constexpr uint32_t kMaxNodesPerTree = 1u << 24;
+constexpr uint32_t kBigLeaf = 255u;
+
+struct DTri {
+  float p0x, p0y, p0z;
+  uint32_t p0w;  // out-of-line leaf size for the first triangle of a big leaf
+  float e1x, e1y, e1z, e1w;
+  float e2x, e2y, e2z, e2w;
+};
+static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
+
+struct DTriN {
+  float n0[4], n1[4], n2[4];
+};
+static_assert(sizeof(DTriN) == 48, "DTriN must be 48 bytes");
+
+struct DInst {
+  float mi[12];        // world -> object, rows of a 3x4
+  float m[12];         // object -> world
+  uint32_t node_base;  // index of this instance's BLAS root in the node array
+  uint32_t tri_base;   // index of its triangle 0 in the DTri / DTriN arrays
+  uint32_t material;   // index into the material table
+  uint32_t kind;       // per-material kernel (MIRT_MAT_*), 0 when unused
+  uint32_t kind_data;  // row in that kernel's table
+  uint32_t root_start, root_count;  // primitive range of the BLAS root (light sampling)
+  uint32_t pad;
+};
+static_assert(sizeof(DInst) == 128, "DInst must be 128 bytes");
+
+// Per-slot path state.  Records are 16-B multiples so a slot is read with
+// whole dwordx4 loads; slots are gathered through the queues' index lists.
+struct DRay {  // same bytes as MirtRay
+  float px, py, pz, dx;
+  float dy, dz;
+  uint32_t last_inst, last_prim;
+};
+static_assert(sizeof(DRay) == 32, "DRay must be 32 bytes");
+
+struct DHit {
+  float px, py, pz;
+  uint32_t inst_ff;  // instance id | front_face << 31
+  float nx, ny, nz;
+  uint32_t prim;
+};
+static_assert(sizeof(DHit) == 32, "DHit must be 32 bytes");
+
+struct DPath {
+  float rx, ry, rz;   // radiance
+  uint32_t bounces;
+  float tx, ty, tz;   // throughput
+  uint32_t source;    // sample source index; 0xFFFFFFFF = slot holds no sample
+  uint32_t rng[4];
+};
+static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
+
+struct DShadow {  // archive ShadowData
+  float dx, dy, dz, prob;
+  float rx, ry, rz, pad;
+};
+static_assert(sizeof(DShadow) == 32, "DShadow must be 32 bytes");
+
+struct DMaterial {  // the fields of MirtMaterial the kernels read
+  float colour[4];
+  float emissive[4];
+  float metallic, roughness, ior, transmission;
+  float pad[4];
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
+
+// Everything a traversal needs, passed by value to the kernels.
+struct DScene {
+  const DNode *tlas;          // node i at tlas[i]
+  const uint32_t *tlas_big;   // out-of-line leaf sizes, one per TLAS node
+  const uint32_t *tlas_to_inst;
+  const DInst *inst;
+  const DNode *blas;          // all BLAS node blocks
+  const DTri *tri;
+  const DTriN *trin;
+  const DMaterial *mat;
+  const uint32_t *lights;     // instance ids
+  uint32_t n_lights;          // 0 when the scene has none
+  const float *lambertian;    // 4 floats per row (albedo)
+  const float *metallic;      // 8 floats per row (albedo, fuzz, pad)
+  const float *dielectric;    // 8 floats per row (albedo, ir, pad)
+  const float *emissive;      // 4 floats per row (albedo)
+};
+
+struct DCounts {
+  unsigned long long rays, tlas_nodes, instance_visits, blas_nodes, triangles;
+};
+
+}  // namespace mirt

@@ -1,0 +1,400 @@
+// capi.cpp — extern "C" surface of the host scene model and the five
+// benchmark scene configurations.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <sys/stat.h>
+
+#include "host.hpp"
+#include "mirt_host.h"
+
+using namespace mirth;
+
+struct mirth_scene {
+  Scene scene;
+  std::string error;
+  bool bound = false;
+};
+
+namespace {
+
+const char kMagic[8] = {'M', 'I', 'R', 'T', 'M', 'E', 'S', 'H'};
+
+bool write_model_file(const std::string &path, const ObjModel &m, std::string &err) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) {
+    err = "cannot write " + path;
+    return false;
+  }
+  uint32_t hdr[3] = {(uint32_t)m.positions.size(), (uint32_t)m.normals.size(), (uint32_t)m.indices.size()};
+  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 4, 3, f) == 3 &&
+            fwrite(m.positions.data(), 4, m.positions.size(), f) == m.positions.size() &&
+            fwrite(m.normals.data(), 4, m.normals.size(), f) == m.normals.size() &&
+            fwrite(m.indices.data(), 4, m.indices.size(), f) == m.indices.size();
+  fclose(f);
+  if (!ok) err = "short write to " + path;
+  return ok;
+}
+
+bool read_model_file(const std::string &path, ObjModel &m, std::string &err) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) {
+    err = "cannot open " + path;
+    return false;
+  }
+  char magic[8];
+  uint32_t hdr[3];
+  bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 && fread(hdr, 4, 3, f) == 3;
+  if (ok) {
+    m.positions.resize(hdr[0]);
+    m.normals.resize(hdr[1]);
+    m.indices.resize(hdr[2]);
+    ok = fread(m.positions.data(), 4, hdr[0], f) == hdr[0] && fread(m.normals.data(), 4, hdr[1], f) == hdr[1] &&
+         fread(m.indices.data(), 4, hdr[2], f) == hdr[2];
+  }
+  fclose(f);
+  if (!ok) err = "bad MIRTMESH file " + path;
+  if (ok) {
+    for (uint32_t i : m.indices)
+      if ((size_t)i * 3 + 2 >= m.positions.size()) {
+        err = "index out of range in " + path;
+        return false;
+      }
+  }
+  return ok;
+}
+
+bool file_exists(const std::string &p) {
+  struct stat st;
+  return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+// Find <dir>/<name>.obj or <dir>/<name>.mirtmesh; returns a mesh id or -1.
+int load_asset(mirth_scene *s, const std::string &dir, const std::string &name) {
+  std::string obj = dir + "/" + name + ".obj";
+  if (file_exists(obj)) return mirth_load_mesh_obj(s, obj.c_str());
+  std::string mm = dir + "/" + name + ".mirtmesh";
+  if (file_exists(mm)) return mirth_load_mesh_model_file(s, mm.c_str());
+  s->error = "asset " + name + " not found in " + dir;
+  return -1;
+}
+
+MirtTransform xform(float s, float rx, float ry, float rz, float tx, float ty, float tz) {
+  MirtTransform t;
+  t.scale[0] = t.scale[1] = t.scale[2] = s;
+  t.scale[3] = s;
+  t.rotation[0] = rx; t.rotation[1] = ry; t.rotation[2] = rz; t.rotation[3] = 0.0f;
+  t.translation[0] = tx; t.translation[1] = ty; t.translation[2] = tz; t.translation[3] = 0.0f;
+  return t;
+}
+
+MirtMaterial pbr(float r, float g, float b, float metallic, float roughness, float transmission, float ior) {
+  MirtMaterial m = default_material();
+  m.colour[0] = r; m.colour[1] = g; m.colour[2] = b; m.colour[3] = 1.0f;
+  m.metallic = metallic;
+  m.roughness = roughness;
+  m.transmission = transmission;
+  m.ior = ior;
+  return m;
+}
+
+bool validate_model(const ObjModel &m, std::string &err) {
+  if (m.positions.size() % 3 || m.normals.size() % 3 || m.indices.size() % 3) {
+    err = "model arrays must have 3 entries per element";
+    return false;
+  }
+  for (uint32_t i : m.indices)
+    if ((size_t)i * 3 + 2 >= m.positions.size()) {
+      err = "model index out of range";
+      return false;
+    }
+  if (m.indices.empty()) {
+    err = "model has no triangles";
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+mirth_scene *mirth_scene_new(void) { return new (std::nothrow) mirth_scene(); }
+void mirth_scene_free(mirth_scene *s) { delete s; }
+const char *mirth_last_error(const mirth_scene *s) { return s ? s->error.c_str() : "null scene"; }
+
+int mirth_load_mesh_obj(mirth_scene *s, const char *path) {
+  if (!s || !path) return -1;
+  std::string key = std::string("TOBJ:") + path;
+  auto it = s->scene.by_desc.find(key);
+  if (it != s->scene.by_desc.end()) return (int)it->second;
+  ObjModel m;
+  if (!load_obj_first_model(path, m, s->error)) return -1;
+  return (int)s->scene.add_mesh(key, Mesh::from_model(m));
+}
+
+int mirth_load_mesh_rect(mirth_scene *s) { return s ? (int)s->scene.add_mesh("Rect", Mesh::rect()) : -1; }
+int mirth_load_mesh_cube(mirth_scene *s) { return s ? (int)s->scene.add_mesh("Cube", Mesh::cube()) : -1; }
+
+int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positions, uint32_t n_positions,
+                          const float *normals, uint32_t n_normals, const uint32_t *indices,
+                          uint32_t n_indices) {
+  if (!s || !name || !positions || !indices) return -1;
+  ObjModel m;
+  m.positions.assign(positions, positions + n_positions);
+  if (normals) m.normals.assign(normals, normals + n_normals);
+  m.indices.assign(indices, indices + n_indices);
+  if (!validate_model(m, s->error)) return -1;
+  return (int)s->scene.add_mesh(std::string("MODEL:") + name, Mesh::from_model(m));
+}
+
+int mirth_load_mesh_model_file(mirth_scene *s, const char *path) {
+  if (!s || !path) return -1;
+  std::string key = std::string("MODELFILE:") + path;
+  auto it = s->scene.by_desc.find(key);
+  if (it != s->scene.by_desc.end()) return (int)it->second;
+  ObjModel m;
+  if (!read_model_file(path, m, s->error) || !validate_model(m, s->error)) return -1;
+  return (int)s->scene.add_mesh(key, Mesh::from_model(m));
+}
+
+int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed) {
+  if (!s || n_u < 3 || n_v < 3) return -1;
+  std::string key = "KNOT:" + std::to_string(n_u) + "x" + std::to_string(n_v) + ":" + std::to_string(seed);
+  auto it = s->scene.by_desc.find(key);
+  if (it != s->scene.by_desc.end()) return (int)it->second;
+  return (int)s->scene.add_mesh(key, Mesh::from_model(make_knot_model(n_u, n_v, seed)));
+}
+
+int mirth_add_material(mirth_scene *s, const MirtMaterial *m) {
+  if (!s || !m) return -1;
+  return (int)s->scene.add_material(*m);
+}
+void mirth_default_material(MirtMaterial *out) {
+  if (out) *out = default_material();
+}
+void mirth_default_camera(MirtCamera *out) {
+  if (out) *out = default_camera();
+}
+
+int mirth_spawn(mirth_scene *s, const MirtTransform *t, int mesh_id, int material_id) {
+  if (!s || !t || mesh_id < 0 || material_id < 0) return -1;
+  if ((size_t)mesh_id >= s->scene.meshes.size() || (size_t)material_id >= s->scene.material_server.size()) {
+    s->error = "spawn: unknown mesh or material id";
+    return -1;
+  }
+  s->bound = false;
+  return (int)s->scene.spawn(*t, (uint32_t)mesh_id, (uint32_t)material_id);
+}
+
+int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3], int with_ceiling_light) {
+  if (!s || !dims || !pos) return -1;
+  s->bound = false;
+  spawn_cornell(s->scene, {dims[0], dims[1], dims[2]}, {pos[0], pos[1], pos[2]}, with_ceiling_light != 0);
+  return 0;
+}
+
+int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32_t dragon_n_u,
+                       uint32_t dragon_n_v, MirthConfigInfo *info) {
+  if (!s || !info || config < 1 || config > 5) return -1;
+  const std::string dir = asset_dir ? asset_dir : ".";
+  if (dragon_n_u == 0) dragon_n_u = 2722;  // 2 * 2722 * 160 = 871 040 triangles
+  if (dragon_n_v == 0) dragon_n_v = 160;
+  memset(info, 0, sizeof(*info));
+  info->seed = 0x5EED0000u + (uint32_t)config;
+  info->shade_mode = MIRT_SHADE_UBER;
+  Scene &sc = s->scene;
+  s->bound = false;
+
+  auto load_dragon = [&]() -> int {
+    std::string obj = dir + "/dragon.obj", mm = dir + "/dragon.mirtmesh";
+    if (file_exists(obj)) return mirth_load_mesh_obj(s, obj.c_str());
+    if (file_exists(mm)) return mirth_load_mesh_model_file(s, mm.c_str());
+    info->procedural_dragon = 1;
+    return mirth_load_mesh_knot(s, dragon_n_u, dragon_n_v, 1);
+  };
+
+  switch (config) {
+    case 1: {
+      // suzanne as one BLAS at (0,0,3) under a rect light
+      int suz = load_asset(s, dir, "suzanne");
+      if (suz < 0) return -1;
+      int rect = mirth_load_mesh_rect(s);
+      MirtMaterial grey = pbr(0.8f, 0.8f, 0.8f, 0.0f, 1.0f, 0.0f, 1.5f);  // src/scenes.rs:27-33
+      MirtMaterial light = pbr(1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 0.0f, 1.5f); // src/scenes.rs:43-49
+      light.colour[3] = 0.0f;
+      light.emissive[0] = light.emissive[1] = light.emissive[2] = 20.0f;
+      uint32_t g = sc.add_material(grey), l = sc.add_material(light);
+      sc.spawn(xform(1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 3.0f), (uint32_t)suz, g);
+      MirtTransform lt = xform(1.0f, 1.57079632679489661923f, 0.0f, 0.0f, 0.0f, 1.8f, 3.0f);
+      lt.scale[0] = 2.0f;
+      lt.scale[1] = 2.0f;
+      sc.spawn(lt, (uint32_t)rect, l);
+      info->width = 256; info->height = 256; info->spp = 1; info->max_bounces = 4;
+      break;
+    }
+    case 2: {
+      // open Cornell box + three teapots: Lambertian-like, Metallic, Dielectric
+      int tea = load_asset(s, dir, "teapot");
+      if (tea < 0) return -1;
+      spawn_cornell(sc, {3.0f, 3.0f, 3.0f}, {0.0f, 0.0f, 3.0f}, false);
+      uint32_t lam = sc.add_material(pbr(0.8f, 0.6f, 0.2f, 0.0f, 1.0f, 0.0f, 1.5f));
+      uint32_t met = sc.add_material(pbr(0.9f, 0.9f, 0.9f, 1.0f, 0.01f, 0.0f, 1.5f));
+      uint32_t die = sc.add_material(pbr(1.0f, 1.0f, 1.0f, 0.0f, 0.1f, 1.0f, 1.5f));
+      sc.spawn(xform(0.45f, 0.0f, 0.6f, 0.0f, -0.95f, -1.05f, 3.3f), (uint32_t)tea, lam);
+      sc.spawn(xform(0.45f, 0.0f, 0.0f, 0.0f, 0.0f, -1.05f, 2.6f), (uint32_t)tea, met);
+      sc.spawn(xform(0.45f, 0.0f, -0.6f, 0.0f, 0.95f, -1.05f, 3.3f), (uint32_t)tea, die);
+      info->width = 1920; info->height = 1080; info->spp = 64; info->max_bounces = 8;
+      info->shade_mode = MIRT_SHADE_CLASSIC;
+      break;
+    }
+    case 3:
+    case 5: {
+      // simple_scene (src/scenes.rs:136-193): cube mesh is loaded but unused,
+      // three materials are registered before the Cornell box's five.
+      mirth_load_mesh_cube(s);
+      int dragon = load_dragon();
+      if (dragon < 0) return -1;
+      MirtMaterial gold = pbr(1.0f, 0.99f, 0.0f, 0.0f, 0.4f, 0.0f, 1.5f);
+      MirtMaterial glass = pbr(1.0f, 1.0f, 1.0f, 0.2f, 0.1f, 0.0f, 1.5f);
+      if (config == 5) {  // dielectric-heavy variant
+        glass.metallic = 0.0f;
+        glass.transmission = 1.0f;
+      }
+      MirtMaterial gray = pbr(0.8f, 0.8f, 0.8f, 0.0f, 1.0f, 0.0f, 1.5f);
+      sc.add_material(gold);
+      uint32_t glass_id = sc.add_material(glass);
+      sc.add_material(gray);
+      spawn_cornell(sc, {3.0f, 3.0f, 3.0f}, {0.0f, 0.0f, 3.0f}, config == 5);
+      MirtTransform t = xform(1.0f, 0.0f, 0.0f, 0.0f, 0.0f, -0.89f, 2.75f);
+      sc.spawn(t, (uint32_t)dragon, glass_id);
+      if (config == 3) {
+        info->width = 1920; info->height = 1080; info->spp = 256; info->max_bounces = 8;
+      } else {
+        info->width = 3840; info->height = 2160; info->spp = 1024; info->max_bounces = 8;
+        info->shade_mode = MIRT_SHADE_CLASSIC;
+        info->nee = 1;
+      }
+      break;
+    }
+    case 4: {
+      // grid_scene (src/scenes.rs:676-786) widened to 10x10x10 instances,
+      // meshes cycled dragon/teapot/suzanne/cube, seeded instead of OS entropy.
+      int suz = load_asset(s, dir, "suzanne");
+      int tea = load_asset(s, dir, "teapot");
+      if (suz < 0 || tea < 0) return -1;
+      int dragon = load_dragon();
+      int cube = mirth_load_mesh_cube(s);
+      if (dragon < 0) return -1;
+      const int mesh_ids[4] = {dragon, tea, suz, cube};
+      SplitMix64 rng(info->seed);
+      std::vector<uint32_t> lam, met, die, emi;
+      for (int i = 0; i < 15; ++i) lam.push_back(sc.add_material(pbr(rng.unit(), rng.unit(), rng.unit(), 0.0f, 1.0f, 0.0f, 1.5f)));
+      for (int i = 0; i < 15; ++i) {
+        float r = rng.unit(), g = rng.unit(), b = rng.unit();
+        float fuzz = rng.range(-1.0f, 1.0f);
+        fuzz = fuzz < 0.0f ? 0.0f : fuzz;
+        met.push_back(sc.add_material(pbr(r, g, b, 1.0f, fuzz, 0.0f, 1.5f)));
+      }
+      for (int i = 0; i < 15; ++i) {
+        MirtMaterial m = pbr(1.0f, 1.0f, 1.0f, 0.0f, 1.0f, 0.0f, 1.5f);
+        // the archive scene uses 800x emission against a dark sky; scaled to
+        // the live sky radiance of 10 so lights and sky are comparable
+        m.emissive[0] = rng.range(0.4f, 1.0f) * 20.0f;
+        m.emissive[1] = rng.range(0.4f, 1.0f) * 20.0f;
+        m.emissive[2] = rng.range(0.4f, 1.0f) * 20.0f;
+        emi.push_back(sc.add_material(m));
+      }
+      for (int i = 0; i < 15; ++i) {
+        float r = rng.unit(), g = rng.unit(), b = rng.unit();
+        die.push_back(sc.add_material(pbr(r, g, b, 0.0f, 0.05f, 1.0f, rng.range(1.0f, 1.8f))));
+      }
+      int k = 0;
+      for (int x = 1; x <= 10; ++x)
+        for (int y = 0; y < 10; ++y)
+          for (int z = 1; z <= 10; ++z) {
+            float w = rng.range(0.0f, 4.1f);  // weights 2 : 1 : 1 : 0.1
+            uint32_t mat = w < 2.0f ? lam[rng.below(15)]
+                                    : (w < 3.0f ? met[rng.below(15)] : (w < 4.0f ? die[rng.below(15)] : emi[rng.below(15)]));
+            int mesh = mesh_ids[(k++) & 3];
+            float sc1 = rng.range(0.5f, 1.25f);
+            float rx = rng.range(0.0f, 3.14159265f), ry = rng.range(0.0f, 3.14159265f), rz = rng.range(0.0f, 3.14159265f);
+            float tx = (float)x * 2.0f + rng.range(-0.25f, 0.25f) - 11.0f;  // centred on the view axis
+            float ty = (float)y * 2.0f + rng.range(-0.25f, 0.25f) - 9.0f;
+            float tz = (float)z * 2.0f + rng.range(-0.25f, 0.25f) + 4.0f;
+            sc.spawn(xform(sc1, rx, ry, rz, tx, ty, tz), (uint32_t)mesh, mat);
+          }
+      info->width = 1920; info->height = 1080; info->spp = 64; info->max_bounces = 8;
+      break;
+    }
+  }
+  return 0;
+}
+
+int mirth_bind(mirth_scene *s) {
+  if (!s) return -1;
+  s->scene.bind();
+  s->bound = true;
+  if (s->scene.instances.empty()) {
+    s->error = "bind: no instances";
+    return -1;
+  }
+  return 0;
+}
+
+int mirth_scene_desc(const mirth_scene *s, MirtSceneDesc *out) {
+  if (!s || !out || !s->bound) return -1;
+  s->scene.fill_desc(*out);
+  return 0;
+}
+
+int mirth_make_sample_sources(uint32_t width, uint32_t height, uint64_t seed, int shuffle,
+                              MirtSampleSource *out) {
+  if (!out || width == 0 || height == 0) return -1;
+  std::vector<MirtSampleSource> v = make_sample_sources(width, height, seed, shuffle);
+  memcpy(out, v.data(), v.size() * sizeof(MirtSampleSource));
+  return 0;
+}
+
+int mirth_obj_to_model_file(const char *obj_path, const char *out_path) {
+  if (!obj_path || !out_path) return -1;
+  ObjModel m;
+  std::string err;
+  if (!load_obj_first_model(obj_path, m, err)) return -1;
+  return write_model_file(out_path, m, err) ? 0 : -1;
+}
+
+int mirth_parse_obj_counts(const char *text, size_t len, uint32_t *n_positions, uint32_t *n_normals,
+                           uint32_t *n_triangles) {
+  if (!text) return -1;
+  ObjModel m;
+  std::string err;
+  if (!parse_obj_first_model(text, len, m, err)) return -1;
+  if (n_positions) *n_positions = (uint32_t)m.positions.size() / 3;
+  if (n_normals) *n_normals = (uint32_t)m.normals.size() / 3;
+  if (n_triangles) *n_triangles = (uint32_t)m.indices.size() / 3;
+  return 0;
+}
+
+int mirth_mesh_counts(const mirth_scene *s, int mesh_id, uint32_t *n_vertices, uint32_t *n_faces,
+                      uint32_t *n_nodes) {
+  if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size()) return -1;
+  const MeshData &d = s->scene.meshes[mesh_id];
+  if (n_vertices) *n_vertices = (uint32_t)d.mesh.positions.size();
+  if (n_faces) *n_faces = (uint32_t)d.mesh.n_faces();
+  if (n_nodes) *n_nodes = (uint32_t)d.nodes.size();
+  return 0;
+}
+
+int mirth_mesh_copy(const mirth_scene *s, int mesh_id, float *positions4, float *normals4, uint32_t *faces4,
+                    MirtBVHNode *nodes) {
+  if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size()) return -1;
+  const MeshData &d = s->scene.meshes[mesh_id];
+  if (positions4) memcpy(positions4, d.mesh.positions.data(), d.mesh.positions.size() * 16);
+  if (normals4) memcpy(normals4, d.mesh.normals.data(), d.mesh.normals.size() * 16);
+  if (faces4) memcpy(faces4, d.mesh.faces.data(), d.mesh.faces.size() * 4);
+  if (nodes) memcpy(nodes, d.nodes.data(), d.nodes.size() * sizeof(MirtBVHNode));
+  return 0;
+}
+
+}  // extern "C"

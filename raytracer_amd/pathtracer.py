@@ -1,0 +1,176 @@
+"""Device context: the role of the reference's PathtracerState + PathtracerPhase +
+pathtracer_phase_execute (src/pathtracer_state.rs:96, src/pathtracer_manager.rs:74,195),
+driven through the C ABI of libmirt.  Every call goes to the HIP library; there is
+no CPU fallback — a missing library or device raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+
+
+class MirtError(RuntimeError):
+    pass
+
+
+def default_params(**kw):
+    """MirtParams holding the reference's literals; keyword arguments override."""
+    p = ffi.Params()
+    ffi.device_lib().mirt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Pathtracer:
+    def __init__(self, device=0):
+        self._L = ffi.device_lib()
+        h = C.c_void_p()
+        rc = self._L.mirt_create(device, C.byref(h))
+        if rc != 0:
+            raise MirtError(f"mirt_create(device={device}): {self._L.mirt_status_string(rc).decode()}")
+        self._h = h
+        self.n_sources = 0
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mirt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MirtError(f"{what}: {self._L.mirt_status_string(rc).decode()}: "
+                            f"{self._L.mirt_last_error(self._h).decode()}")
+
+    # ---- scene / state -------------------------------------------------
+    def upload_scene(self, arrays):
+        d = ffi.desc_from_arrays(arrays)
+        self._check(self._L.mirt_scene_upload(self._h, C.byref(d)), "mirt_scene_upload")
+
+    def create_state(self, width, height, threads, sources, params):
+        sources = np.ascontiguousarray(sources, ffi.SampleSource)
+        self._check(self._L.mirt_state_create(self._h, width, height, threads, sources.ctypes.data, len(sources),
+                                              C.byref(params)), "mirt_state_create")
+        self.n_sources = len(sources)
+        self.width, self.height = width, height
+
+    def set_camera(self, camera):
+        cam = np.ascontiguousarray(camera, ffi.Camera)
+        self._check(self._L.mirt_camera_set(self._h, cam.ctypes.data), "mirt_camera_set")
+
+    def reset_accum(self):
+        self._check(self._L.mirt_reset_accum(self._h), "mirt_reset_accum")
+
+    def set_sample_range(self, first_sample):
+        self._check(self._L.mirt_set_sample_range(self._h, first_sample), "mirt_set_sample_range")
+
+    # ---- rendering -----------------------------------------------------
+    def step(self, n_frames=1):
+        self._check(self._L.mirt_step(self._h, n_frames), "mirt_step")
+
+    def render_spp(self, spp):
+        self._check(self._L.mirt_render_spp(self._h, spp), "mirt_render_spp")
+
+    def synchronize(self):
+        self._check(self._L.mirt_synchronize(self._h), "mirt_synchronize")
+
+    def read_output(self):
+        rgb = np.zeros(self.width * self.height, "<u4")
+        self._check(self._L.mirt_read_output(self._h, rgb.ctypes.data, rgb.size), "mirt_read_output")
+        return rgb
+
+    def read_accum(self):
+        sum4 = np.zeros(4 * self.n_sources, "<u4")
+        count = np.zeros(self.n_sources, "<u4")
+        self._check(self._L.mirt_read_accum(self._h, sum4.ctypes.data, count.ctypes.data, self.n_sources),
+                    "mirt_read_accum")
+        return sum4, count
+
+    def copy_accum_to_device(self, dev_sum4_ptr, dev_count_ptr):
+        self._check(self._L.mirt_copy_accum_to_device(self._h, dev_sum4_ptr, dev_count_ptr, self.n_sources),
+                    "mirt_copy_accum_to_device")
+
+    def load_accum_from_device(self, dev_sum4_ptr, dev_count_ptr):
+        self._check(self._L.mirt_load_accum_from_device(self._h, dev_sum4_ptr, dev_count_ptr, self.n_sources),
+                    "mirt_load_accum_from_device")
+
+    # ---- ray sets ------------------------------------------------------
+    def trace_closest(self, rays, want_counts=False):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        out = np.zeros(len(rays), ffi.HitId)
+        c = ffi.TraversalCounts()
+        self._check(self._L.mirt_trace_closest(self._h, rays.ctypes.data, len(rays), out.ctypes.data,
+                                               C.byref(c) if want_counts else None), "mirt_trace_closest")
+        return (out, c) if want_counts else out
+
+    def trace_any(self, rays, tmax, want_counts=False):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        tmax = np.ascontiguousarray(tmax, "<f4")
+        out = np.zeros(len(rays), ffi.HitId)
+        c = ffi.TraversalCounts()
+        self._check(self._L.mirt_trace_any(self._h, rays.ctypes.data, tmax.ctypes.data, len(rays), out.ctypes.data,
+                                           C.byref(c) if want_counts else None), "mirt_trace_any")
+        return (out, c) if want_counts else out
+
+    def bench_trace_closest(self, rays, repeats=10):
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        ms = C.c_double()
+        self._check(self._L.mirt_bench_trace_closest(self._h, rays.ctypes.data, len(rays), repeats, C.byref(ms)),
+                    "mirt_bench_trace_closest")
+        return ms.value
+
+    def dump_extension_rays(self, capacity):
+        out = np.zeros(capacity, ffi.Ray)
+        n = C.c_size_t()
+        self._check(self._L.mirt_dump_extension_rays(self._h, out.ctypes.data, capacity, C.byref(n)),
+                    "mirt_dump_extension_rays")
+        return out[: n.value]
+
+    # ---- diagnostics ---------------------------------------------------
+    def stats(self):
+        s = ffi.Stats()
+        self._check(self._L.mirt_stats(self._h, C.byref(s)), "mirt_stats")
+        return s
+
+    def stats_reset(self):
+        self._check(self._L.mirt_stats_reset(self._h), "mirt_stats_reset")
+
+    def set_counting(self, enabled):
+        self._check(self._L.mirt_set_counting(self._h, int(enabled)), "mirt_set_counting")
+
+    def set_event_timing(self, enabled):
+        self._check(self._L.mirt_set_event_timing(self._h, int(enabled)), "mirt_set_event_timing")
+
+    def math_selftest(self, a, b, c):
+        a = np.ascontiguousarray(a, "<f4")
+        b = np.ascontiguousarray(b, "<f4")
+        c = np.ascontiguousarray(c, "<f4")
+        out = np.zeros(6 * len(a), "<f4")
+        self._check(self._L.mirt_math_selftest(self._h, a.ctypes.data, b.ctypes.data, c.ctypes.data, len(a),
+                                               out.ctypes.data), "mirt_math_selftest")
+        return out
+
+
+def partition_samples(spp, world_size, rank):
+    """Samples-per-pixel partition over GPUs: rank r renders sample numbers
+    [first, first + n) of every source.  The union over ranks is [0, spp)."""
+    base, extra = divmod(spp, world_size)
+    n = base + (1 if rank < extra else 0)
+    first = rank * base + min(rank, extra)
+    return first, n
