@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the wavefront path-tracing hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json's metric configuration, "dragon.obj 1080p, 8 bounces"):
+the reference's simple_scene — open Cornell box + dragon — at 1920x1080 with
+the reference's shuffled sample-source order, 8 bounces, sky 10.  dragon.obj is
+absent from the reference checkout; unless tests/golden/dragon.{obj,mirtmesh}
+exists, a deterministic procedural dragon-class mesh (871 040 triangles) stands
+in, and `config.geometry` says so.
+
+A step renders `--spp-per-step` samples for every pixel through the whole
+pipeline (sample/new_ray -> extend -> shade, to completion) with all inputs
+resident in HBM.  With N > 1 every rank renders its own sample numbers
+(samples-per-pixel are partitioned, scene replicated: weak scaling) and the
+accumulators are combined by one RCCL all-reduce inside the timed region.
+
+Prints ONE JSON line: Mrays/s (extend + connect rays actually traced, summed
+over ranks, divided by the slowest rank's wall time), plus
+  roofline      the dominant kernel (extend): algorithmic bytes per launch
+                (reference-layout traffic model x visit counts counted on the
+                device in an untimed replay of the same samples) / mean launch
+                duration from HIP events on the kernels' stream
+  cpu_baseline  the CPU oracle on the host cores, on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    return ap.parse_args()
+
+
+def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
+    """The CPU oracle (a port of the reference's kernels, OpenMP over samples) on
+    this host's cores, on the first sources of the same workload at 1 spp."""
+    from oracle import pyoracle as po
+    sc = po.Scene(arrays)
+    prm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=0)
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or (os.cpu_count() or 1)))
+    n = 4096
+    t0 = time.perf_counter()
+    _, _, st = sc.render(cam, src[:n].copy(), W, H, prm, 0, 1, threads=threads)
+    dt = time.perf_counter() - t0
+    rate = (st.extend_rays + st.connect_rays) / max(dt, 1e-9)
+    per_source = (st.extend_rays + st.connect_rays) / n
+    n2 = int(min(len(src), max(n, target_seconds * rate / max(per_source, 1e-9))))
+    t0 = time.perf_counter()
+    _, _, st = sc.render(cam, src[:n2].copy(), W, H, prm, 0, 1, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = st.extend_rays + st.connect_rays
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"first {n2} of {len(src)} sample sources of the same workload, 1 spp, {rays} rays in {dt:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    from raytracer_amd import distributed, host, pathtracer
+
+    arrays, info = host.build_config_scene(args.config)
+    W = args.width or info.width
+    H = args.height or info.height
+    src = host.make_sample_sources(W, H, info.seed, shuffle=2)
+    cam = host.default_camera(W, H)
+    params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
+                                       nee=info.nee)
+    pt = pathtracer.Pathtracer(local_rank)
+    pt.upload_scene(arrays)
+    pt.create_state(W, H, W * H, src, params)
+    pt.set_camera(cam)
+
+    spp_step = args.spp_per_step
+    total_steps = args.warmup + args.steps
+    # rank r owns sample numbers [r * total, (r + 1) * total) * spp_step
+    first = rank * total_steps * spp_step
+    pt.set_sample_range(first)
+    for _ in range(args.warmup):
+        pt.render_spp(spp_step)
+    pt.synchronize()
+    if dist is not None:
+        # warm the collective too
+        distributed.reduce_device_accumulators(pt, device)
+    pt.stats_reset()
+    pt.set_event_timing(True)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    pt.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pt.render_spp(spp_step)
+    pt.synchronize()
+    reduce_s = 0.0
+    if dist is not None:
+        reduce_s = distributed.reduce_device_accumulators(pt, device)
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    pt.set_event_timing(False)
+    st = pt.stats()
+    rays = int(st.extend_rays + st.connect_rays)
+    samples = int(st.finished_samples)
+
+    if dist is not None:
+        t = torch.tensor([elapsed, float(rays), float(samples), reduce_s], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        reduce_s = float(tmax[3])
+        rays = int(tsum[1])
+        samples = int(tsum[2])
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: replay the timed samples with visit counting
+        ext_ms = st.extend_ms / max(st.extend_launches, 1)
+        pt.stats_reset()
+        pt.set_counting(True)
+        pt.set_sample_range(first + args.warmup * spp_step)
+        for _ in range(args.steps):
+            pt.render_spp(spp_step)
+        pt.set_counting(False)
+        cst = pt.stats()
+        counts = cst.extend_counts
+        assert counts.rays == st.extend_rays, (counts.rays, st.extend_rays)
+        alg_bytes = counts.algorithmic_bytes(112)  # 112 B fixed per ray + 64 B/node + 76 B/instance visit + 160 B/triangle
+        per_launch = alg_bytes / max(st.extend_launches, 1)
+        achieved = per_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                if tj.get("workload") == f"config{args.config} {W}x{H}":
+                    traffic = tj.get("hbm_bytes_per_extend_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": per_launch, "launch_ms": ext_ms,
+                    "launches": int(st.extend_launches),
+                    "per_ray": {"tlas_nodes": counts.tlas_nodes / max(counts.rays, 1),
+                                "instance_visits": counts.instance_visits / max(counts.rays, 1),
+                                "blas_nodes": counts.blas_nodes / max(counts.rays, 1),
+                                "triangles": counts.triangles / max(counts.rays, 1)}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
+        geometry = "procedural dragon-class knot, 871040 triangles" if info.procedural_dragon else "dragon asset"
+        out = {
+            "metric": "Mrays/s (extend+shadow), dragon 1080p",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"config{args.config}: simple_scene (open Cornell box + dragon) {W}x{H}, "
+                                   f"{info.max_bounces} bounces, {spp_step} spp per step per GPU, "
+                                   f"{'per-material' if info.shade_mode else 'uber'} shading",
+                       "geometry": geometry, "paths_in_flight": W * H, "parallelism": f"spp split x{world}"},
+            "spp_per_s": samples / (W * H) / elapsed,
+            "rays": rays,
+            "reduce_ms": reduce_s * 1e3,
+            "kernel_ms": {"extend": st.extend_ms, "shade": st.shade_ms, "sample": st.sample_ms,
+                          "connect": st.connect_ms},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    pt.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -163,16 +163,17 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
     const uint32_t i = base + lane_id();
     const bool active = i < count;
     uint32_t slot = 0;
-    bool hit = false;
     uint32_t route = 0;  // classic: queue of the hit material
+    v3 pos = V3(0.0f, 0.0f, 0.0f), dir = V3(1.0f, 1.0f, 1.0f);
+    uint32_t last_inst = kNoPrim, last_prim = kNoPrim;
     if (active) {
       slot = ext[i];
-      v3 pos, dir;
-      uint32_t last_inst, last_prim;
       load_ray(st.ray, slot, pos, dir, last_inst, last_prim);
-      float t = FLT_MAX;
-      BestHit best;
-      hit = traverse<false, COUNT>(sc, pos, dir, last_inst, last_prim, t, best, lc);
+    }
+    float t = FLT_MAX;
+    BestHit best;
+    bool hit = traverse<false, COUNT>(sc, active, pos, dir, last_inst, last_prim, t, best, lc);
+    if (active) {
       DPath *pp = st.path + slot;
       if (!hit) {
         // shaders/ray_extend.slang:34-38: rad += throughput * sky
@@ -412,14 +413,19 @@ __global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, cons
   LaneCounts lc;
   for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
     const uint32_t i = base + lane_id();
-    if (i < n) {
-      v3 pos, dir;
-      uint32_t last_inst, last_prim;
+    const bool active = i < n;
+    v3 pos = V3(0.0f, 0.0f, 0.0f), dir = V3(1.0f, 1.0f, 1.0f);
+    uint32_t last_inst = kNoPrim, last_prim = kNoPrim;
+    float t = FLT_MAX;
+    if (active) {
       load_ray(rays, i, pos, dir, last_inst, last_prim);
-      float t = ANY ? tmax[i] : FLT_MAX;
-      BestHit best;
+      if (ANY) t = tmax[i];
+    }
+    BestHit best;
+    const bool any_found = traverse<ANY, COUNT>(sc, active, pos, dir, last_inst, last_prim, t, best, lc);
+    if (active) {
       MirtHitId o{0xFFFFFFFFu, 0xFFFFFFFFu, FLT_MAX, 0u};
-      if (traverse<ANY, COUNT>(sc, pos, dir, last_inst, last_prim, t, best, lc)) {
+      if (any_found) {
         o.instance_id = best.inst;
         o.triangle_id = best.prim;
         o.t = t;

@@ -1,5 +1,5 @@
 // traverse.h — TLAS -> BLAS threaded (stackless) traversal with ray/box and
-// ray/triangle tests.
+// ray/triangle tests, one ray per lane, scheduled per wave.
 //
 // Same walk as tlasFirstHit / blasFirstHit / rayBoxIntersect /
 // rayTriIntersect of shaders/ray_extend.slang:53-215: start at node 0, go to
@@ -7,7 +7,19 @@
 // every leaf, stop when the walk returns to node 0.  Primitives are visited
 // in ascending index, a hit with t2 == t replaces the previous one, the TLAS
 // box test also rejects boxes entirely behind the ray, the BLAS one does not.
-// What differs is only where the operands come from (see layout.h).
+//
+// What differs from the shader is scheduling, not arithmetic:
+//   - the two nested do-while loops are flattened into ONE wave-uniform loop
+//     whose body does, per lane, a BLAS node step, an instance set-up or a
+//     TLAS node step; lanes inside different instances therefore run the same
+//     instructions, and lanes that are done stay available as helpers;
+//   - a leaf with kCoopLeaf or more triangles (the builder leaves such leaves
+//     behind when its partition puts everything on one side) is tested by the
+//     whole wave, 64 triangles per step, for the one lane that reached it.
+//     A sequential scan accepts every triangle with t2 <= current t, so it
+//     ends on the smallest t2, and among equal t2 on the highest index; the
+//     wave computes exactly that with a min-reduction on (t2, -index).  u, v
+//     and t2 of a triangle do not depend on the current t, so the bits match.
 #pragma once
 
 #include <float.h>
@@ -17,6 +29,8 @@
 
 namespace mirt {
 
+constexpr uint32_t kCoopLeaf = 24u;
+
 struct LaneCounts {
   uint32_t tlas_nodes = 0, instance_visits = 0, blas_nodes = 0, triangles = 0;
 };
@@ -25,6 +39,10 @@ struct BestHit {
   float t, u, v;
   uint32_t prim, inst;
 };
+
+__device__ __forceinline__ uint32_t trv_lane() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
 
 // rayBoxIntersect (shaders/ray_extend.slang:94-111) with 1/dir hoisted out
 // of the walk.  tmin starts at the lowest finite float (float.minValue).
@@ -58,9 +76,10 @@ __device__ __forceinline__ bool ray_box(v3 pos, v3 dinv, const float4 lo, const 
   return tmin <= tmax;
 }
 
-// rayTriIntersect (shaders/ray_extend.slang:53-92); the interpolated vertex is
-// rebuilt afterwards for the winning triangle only.
-__device__ __forceinline__ bool ray_tri(v3 pos, v3 dir, v3 p0, v3 e1, v3 e2, float &t, float &u_out, float &v_out) {
+// rayTriIntersect (shaders/ray_extend.slang:53-92) up to the comparison with
+// the current t: returns false when the triangle is missed, else t2, u, v.
+__device__ __forceinline__ bool ray_tri_uvt(v3 pos, v3 dir, v3 p0, v3 e1, v3 e2, float &t2_out, float &u_out,
+                                            float &v_out) {
   const v3 q = cross3(dir, e2);
   const float alpha = dot3(e1, q);
   if (alpha > -(10e-8f) && alpha < 10e-8f) return false;
@@ -71,9 +90,7 @@ __device__ __forceinline__ bool ray_tri(v3 pos, v3 dir, v3 p0, v3 e1, v3 e2, flo
   const v3 r = cross3(s, e1);
   const float v = f * dot3(dir, r);
   if (v < 0.0f || u + v > 1.0f) return false;
-  const float t2 = f * dot3(e2, r);
-  if (t2 > t || t2 < 0.0f) return false;
-  t = t2;
+  t2_out = f * dot3(e2, r);
   u_out = u;
   v_out = v;
   return true;
@@ -81,77 +98,183 @@ __device__ __forceinline__ bool ray_tri(v3 pos, v3 dir, v3 p0, v3 e1, v3 e2, flo
 
 // Returns true when something was hit.  ANY: stop at the first accepted
 // triangle (connect / shadow query).  COUNT: tally visits into `lc`.
+// Must be called by every lane of the wave; `valid` says whether this lane
+// carries a ray.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool traverse(const DScene &sc, v3 pos, v3 dir, uint32_t last_inst, uint32_t last_prim,
-                                         float &t, BestHit &best, LaneCounts &lc) {
+__device__ __forceinline__ bool traverse(const DScene &sc, bool valid, v3 pos, v3 dir, uint32_t last_inst,
+                                         uint32_t last_prim, float &t, BestHit &best, LaneCounts &lc) {
   const v3 dinv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
   const float4 *tlas4 = reinterpret_cast<const float4 *>(sc.tlas);
   const float4 *blas4 = reinterpret_cast<const float4 *>(sc.blas);
   const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri);
+  const uint32_t lane = trv_lane();
+
   bool found = false;
-  uint32_t cur = 0;
-  do {
-    const float4 lo = tlas4[2 * cur], hi = tlas4[2 * cur + 1];
-    if (COUNT) lc.tlas_nodes++;
-    float tmin_aabb, tmax_aabb;
-    const bool hit_aabb = ray_box(pos, dinv, lo, hi, t, tmin_aabb, tmax_aabb) && (tmax_aabb >= 0.0f || tmin_aabb >= 0.0f);
-    const uint32_t wa = __float_as_uint(lo.w), wb = __float_as_uint(hi.w);
-    const uint32_t leaf = wb >> 24;
-    const uint32_t node = cur;
-    cur = (hit_aabb && leaf == 0u) ? wa : (wb & kSkipMask);
-    if (!hit_aabb || leaf == 0u) continue;
+  bool walking = valid;
+  // TLAS walk
+  uint32_t tcur = 0;
+  bool tlas_done = false;
+  uint32_t slot_i = 0, slot_end = 0;
+  // BLAS walk of the current instance
+  bool in_blas = false;
+  uint32_t bcur = 0, id = 0, node_base = 0, tri_base = 0;
+  bool exclude_here = false;
+  v3 rpos = pos, rdir = dir, rdinv = dinv;
 
-    const uint32_t n_slots = leaf == kBigLeaf ? sc.tlas_big[node] : leaf;
-    for (uint32_t i = wa; i < wa + n_slots; ++i) {
-      const uint32_t id = sc.tlas_to_inst[i];
-      const DInst *inst = &sc.inst[id];
-      if (COUNT) lc.instance_visits++;
-      const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
-      const float4 m1 = reinterpret_cast<const float4 *>(inst->mi)[1];
-      const float4 m2 = reinterpret_cast<const float4 *>(inst->mi)[2];
-      const uint32_t node_base = inst->node_base, tri_base = inst->tri_base;
-      const v3 rpos = V3(__builtin_fmaf(m0.z, pos.z, __builtin_fmaf(m0.y, pos.y, m0.x * pos.x)) + m0.w,
-                         __builtin_fmaf(m1.z, pos.z, __builtin_fmaf(m1.y, pos.y, m1.x * pos.x)) + m1.w,
-                         __builtin_fmaf(m2.z, pos.z, __builtin_fmaf(m2.y, pos.y, m2.x * pos.x)) + m2.w);
-      const v3 rdir = V3(__builtin_fmaf(m0.z, dir.z, __builtin_fmaf(m0.y, dir.y, m0.x * dir.x)),
-                         __builtin_fmaf(m1.z, dir.z, __builtin_fmaf(m1.y, dir.y, m1.x * dir.x)),
-                         __builtin_fmaf(m2.z, dir.z, __builtin_fmaf(m2.y, dir.y, m2.x * dir.x)));
-      const v3 rdinv = V3(1.0f / rdir.x, 1.0f / rdir.y, 1.0f / rdir.z);
-      const bool exclude_here = id == last_inst;
-
-      uint32_t bcur = 0;
-      do {
-        const float4 blo = blas4[2 * (size_t)(node_base + bcur)], bhi = blas4[2 * (size_t)(node_base + bcur) + 1];
+  while (__ballot(walking) != 0ull) {
+    bool big = false;  // this lane reached a leaf for the whole wave to test
+    uint32_t big_start = 0, big_count = 0;
+    if (walking) {
+      if (in_blas) {
+        // ---- one BLAS node (blasFirstHit, shaders/ray_extend.slang:127-158)
+        const size_t ni = (size_t)(node_base + bcur);
+        const float4 blo = blas4[2 * ni], bhi = blas4[2 * ni + 1];
         if (COUNT) lc.blas_nodes++;
         float bt0, bt1;
         const bool bhit = ray_box(rpos, rdinv, blo, bhi, t, bt0, bt1);
         const uint32_t ba = __float_as_uint(blo.w), bb = __float_as_uint(bhi.w);
         const uint32_t bleaf = bb >> 24;
         bcur = (bhit && bleaf == 0u) ? ba : (bb & kSkipMask);
-        if (!bhit || bleaf == 0u) continue;
-
-        uint32_t n_tris = bleaf;
-        if (bleaf == kBigLeaf) n_tris = sc.tri[tri_base + ba].p0w;
-        for (uint32_t p = ba; p < ba + n_tris; ++p) {
-          if (exclude_here && p == last_prim) continue;
-          const float4 a0 = tri4[3 * (size_t)(tri_base + p)];
-          const float4 a1 = tri4[3 * (size_t)(tri_base + p) + 1];
-          const float4 a2 = tri4[3 * (size_t)(tri_base + p) + 2];
-          if (COUNT) lc.triangles++;
-          float u, v;
-          if (ray_tri(rpos, rdir, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t, u, v)) {
-            best.t = t;
-            best.u = u;
-            best.v = v;
-            best.prim = p;
-            best.inst = id;
-            found = true;
-            if (ANY) return true;
+        if (bhit && bleaf != 0u) {
+          uint32_t n_tris = bleaf;
+          if (bleaf == kBigLeaf) n_tris = sc.tri[tri_base + ba].p0w;
+          if (n_tris >= kCoopLeaf) {
+            big = true;
+            big_start = ba;
+            big_count = n_tris;
+          } else {
+            for (uint32_t p = ba; p < ba + n_tris; ++p) {
+              if (exclude_here && p == last_prim) continue;
+              const size_t ti = 3 * (size_t)(tri_base + p);
+              const float4 a0 = tri4[ti], a1 = tri4[ti + 1], a2 = tri4[ti + 2];
+              if (COUNT) lc.triangles++;
+              float t2, u, v;
+              if (ray_tri_uvt(rpos, rdir, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+                  !(t2 > t || t2 < 0.0f)) {
+                t = t2;
+                best.t = t2;
+                best.u = u;
+                best.v = v;
+                best.prim = p;
+                best.inst = id;
+                found = true;
+                if (ANY) {
+                  walking = false;
+                  break;
+                }
+              }
+            }
           }
         }
-      } while (bcur != 0u);
+        if (bcur == 0u) in_blas = false;
+      } else if (slot_i < slot_end) {
+        // ---- enter the next instance of the current TLAS leaf
+        // (shaders/ray_extend.slang:190-203); its matrices were built on the host
+        id = sc.tlas_to_inst[slot_i++];
+        const DInst *inst = &sc.inst[id];
+        if (COUNT) lc.instance_visits++;
+        const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
+        const float4 m1 = reinterpret_cast<const float4 *>(inst->mi)[1];
+        const float4 m2 = reinterpret_cast<const float4 *>(inst->mi)[2];
+        node_base = inst->node_base;
+        tri_base = inst->tri_base;
+        rpos = V3(__builtin_fmaf(m0.z, pos.z, __builtin_fmaf(m0.y, pos.y, m0.x * pos.x)) + m0.w,
+                  __builtin_fmaf(m1.z, pos.z, __builtin_fmaf(m1.y, pos.y, m1.x * pos.x)) + m1.w,
+                  __builtin_fmaf(m2.z, pos.z, __builtin_fmaf(m2.y, pos.y, m2.x * pos.x)) + m2.w);
+        rdir = V3(__builtin_fmaf(m0.z, dir.z, __builtin_fmaf(m0.y, dir.y, m0.x * dir.x)),
+                  __builtin_fmaf(m1.z, dir.z, __builtin_fmaf(m1.y, dir.y, m1.x * dir.x)),
+                  __builtin_fmaf(m2.z, dir.z, __builtin_fmaf(m2.y, dir.y, m2.x * dir.x)));
+        rdinv = V3(1.0f / rdir.x, 1.0f / rdir.y, 1.0f / rdir.z);
+        exclude_here = id == last_inst;
+        bcur = 0u;
+        in_blas = true;
+      } else if (!tlas_done) {
+        // ---- one TLAS node (tlasFirstHit, shaders/ray_extend.slang:173-188)
+        const float4 lo = tlas4[2 * tcur], hi = tlas4[2 * tcur + 1];
+        if (COUNT) lc.tlas_nodes++;
+        float tmin_aabb, tmax_aabb;
+        const bool hit_aabb =
+            ray_box(pos, dinv, lo, hi, t, tmin_aabb, tmax_aabb) && (tmax_aabb >= 0.0f || tmin_aabb >= 0.0f);
+        const uint32_t wa = __float_as_uint(lo.w), wb = __float_as_uint(hi.w);
+        const uint32_t leaf = wb >> 24;
+        if (hit_aabb && leaf != 0u) {
+          slot_i = wa;
+          slot_end = wa + (leaf == kBigLeaf ? sc.tlas_big[tcur] : leaf);
+        }
+        tcur = (hit_aabb && leaf == 0u) ? wa : (wb & kSkipMask);
+        if (tcur == 0u) tlas_done = true;
+      } else {
+        walking = false;
+      }
     }
-  } while (cur != 0u);
+
+    // ---- leaves for the whole wave, one owner lane at a time
+    unsigned long long bigmask = __ballot(big);
+    while (bigmask != 0ull) {
+      const int owner = __ffsll((long long)bigmask) - 1;
+      bigmask &= bigmask - 1ull;
+      const float opx = __shfl(rpos.x, owner), opy = __shfl(rpos.y, owner), opz = __shfl(rpos.z, owner);
+      const float odx = __shfl(rdir.x, owner), ody = __shfl(rdir.y, owner), odz = __shfl(rdir.z, owner);
+      const float ot = __shfl(t, owner);
+      const uint32_t ostart = (uint32_t)__shfl((int)big_start, owner), ocount = (uint32_t)__shfl((int)big_count, owner);
+      const uint32_t otri_base = (uint32_t)__shfl((int)tri_base, owner);
+      const uint32_t oskip = __shfl((int)exclude_here, owner) ? (uint32_t)__shfl((int)last_prim, owner) : 0xFFFFFFFFu;
+      const v3 op = V3(opx, opy, opz), od = V3(odx, ody, odz);
+      // per-lane best over triangles ostart + lane, + 64, ...
+      unsigned long long key = ~0ull;  // (t2 bits << 32) | ~p : min = smallest t2, then highest p
+      float ku = 0.0f, kv = 0.0f, kt = 0.0f;
+      for (uint32_t k = lane; k < ocount; k += 64u) {
+        const uint32_t p = ostart + k;
+        if (p == oskip) continue;
+        const size_t ti = 3 * (size_t)(otri_base + p);
+        const float4 a0 = tri4[ti], a1 = tri4[ti + 1], a2 = tri4[ti + 2];
+        float t2, u, v;
+        if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+            !(t2 > ot || t2 < 0.0f)) {
+          // ANY: first accepted triangle in index order; else smallest t2, ties to the highest index
+          const unsigned long long kk =
+              ANY ? (unsigned long long)p
+                  : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
+          if (kk < key) {
+            key = kk;
+            ku = u;
+            kv = v;
+            kt = t2;
+          }
+          if (ANY) break;  // later triangles of this lane have higher indices
+        }
+      }
+      unsigned long long wkey = key;
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long other = __shfl_xor(wkey, off);
+        wkey = other < wkey ? other : wkey;
+      }
+      if (wkey != ~0ull) {
+        const int winner = __ffsll((long long)__ballot(key == wkey)) - 1;
+        const float wu = __shfl(ku, winner), wv = __shfl(kv, winner), wt = __shfl(kt, winner);
+        const uint32_t wp = ANY ? (uint32_t)wkey : ~(uint32_t)wkey;
+        if ((int)lane == owner) {
+          t = wt;
+          best.t = wt;
+          best.u = wu;
+          best.v = wv;
+          best.prim = wp;
+          best.inst = id;
+          found = true;
+          if (ANY) walking = false;
+        }
+        if (COUNT && (int)lane == owner) {
+          // a scan tests every triangle (ANY: up to the first accepted one) except the excluded one
+          const uint32_t tested = ANY ? (wp - ostart + 1u) : ocount;
+          const bool skipped = oskip >= ostart && oskip < ostart + tested;
+          lc.triangles += tested - (skipped ? 1u : 0u);
+        }
+      } else if (COUNT && (int)lane == owner) {
+        const bool skipped = oskip >= ostart && oskip < ostart + ocount;
+        lc.triangles += ocount - (skipped ? 1u : 0u);
+      }
+    }
+  }
   return found;
 }
 

@@ -1,0 +1,114 @@
+"""The C ABI: both libraries load and export every symbol their headers declare
+(no GPU needed: nothing here launches a kernel), struct sizes match the
+reference layouts, and the N>1 reduction path works over gloo."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+from raytracer_amd import ffi
+
+
+def _declared(header, prefix):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, text)))
+
+
+def test_device_library_exports_every_declared_symbol():
+    names = _declared("mirt.h", "mirt_")
+    assert len(names) >= 25
+    L = ffi.device_lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(ffi.DEVICE_SYMBOLS) == names
+
+
+def test_host_library_exports_every_declared_symbol():
+    names = _declared("mirt_host.h", "mirth_")
+    L = ffi.host_lib()
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_static_archive_is_built():
+    assert os.path.exists(os.path.join(ROOT, "raytracer_amd", "lib", "libmirt.a"))
+
+
+def test_struct_sizes_match_the_reference_layouts():
+    # compile a tiny C program against the header and print sizeof()
+    src = textwrap.dedent("""
+        #include <stdio.h>
+        #include "mirt.h"
+        int main(void) {
+          printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(MirtVertex), sizeof(MirtIndex),
+                 sizeof(MirtBVHNode), sizeof(MirtGeometryOffsets), sizeof(MirtInstance), sizeof(MirtTransform),
+                 sizeof(MirtMaterial), sizeof(MirtCamera), sizeof(MirtSampleSource), sizeof(MirtRay), sizeof(MirtHitId),
+                 sizeof(MirtParams), sizeof(MirtSceneDesc));
+          return 0;
+        }""")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes[:11] == [48, 16, 64, 12, 12, 48, 64, 64, 24, 32, 16]
+    assert sizes[11] == C.sizeof(ffi.Params) and sizes[12] == C.sizeof(ffi.SceneDesc)
+
+
+def test_status_strings_and_default_params_need_no_device():
+    L = ffi.device_lib()
+    assert L.mirt_status_string(0) == b"ok"
+    assert b"scene" in L.mirt_status_string(-6)
+    p = ffi.Params()
+    L.mirt_default_params(C.byref(p))
+    # the reference's literals: sample.slang:71, ray_extend.slang:36, sample.slang:45-47,54
+    assert (p.max_bounces, p.sky_radiance, p.fixed_point_scale) == (128, 10.0, 1000.0)
+    assert np.float32(p.exposure) == np.exp2(np.float32(-2.5))
+
+
+def test_two_rank_gloo_reduce_of_partial_accumulators():
+    """Samples-per-pixel are partitioned over ranks, each rank accumulates its share,
+    and one integer all-reduce combines them: bit-identical to a single-rank render.
+    The ranks' device renders are stood in for by the CPU oracle here (no GPU)."""
+    script = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from raytracer_amd import host, pathtracer
+        from raytracer_amd.distributed import allreduce_accumulators
+        from oracle import pyoracle as po
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        arrays, info = host.build_config_scene(1)
+        sc = po.Scene(arrays)
+        W = H = 32; spp = 3
+        src = host.make_sample_sources(W, H, info.seed); cam = host.default_camera(W, H)
+        prm = po.default_params(max_bounces=4, seed=info.seed)
+        first, n = pathtracer.partition_samples(spp, world, rank)
+        s4, cnt, _ = sc.render(cam, src, W, H, prm, first, n)
+        t4 = torch.from_numpy(s4.view(np.int32).copy()); tc = torch.from_numpy(cnt.view(np.int32).copy())
+        allreduce_accumulators(t4, tc)
+        full4, fullc, _ = sc.render(cam, src, W, H, prm, 0, spp)
+        ok = np.array_equal(t4.numpy().view(np.uint32), full4) and np.array_equal(tc.numpy().view(np.uint32), fullc)
+        print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
+        """ % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.py")
+        open(path, "w").write(script)
+        env = dict(os.environ, OMP_NUM_THREADS="2")
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29617", path],
+                             capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("OK") == 2

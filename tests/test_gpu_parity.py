@@ -1,0 +1,267 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs, against the committed golden vectors, and —
+at full size — through size-independent properties.
+
+Bars: hit instance / primitive ids, t bits, front_face, traversal visit counts,
+fixed-point radiance sums, sample counts and tone-mapped pixels are all compared
+BIT-EXACT (tolerance 0): the kernels and the oracle share one arithmetic
+contract (f32, no implicit contraction, correctly rounded / and sqrt).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, hits_equal, random_rays
+from raytracer_amd import ffi, host, pathtracer
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(GOLDEN, "golden.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def pt():
+    p = pathtracer.Pathtracer(0)
+    yield p
+    p.close()
+
+
+def test_arithmetic_contract_bits(pt):
+    rng = np.random.default_rng(1)
+    n = 200000
+    a = (rng.normal(size=n) * 10.0 ** rng.uniform(-20, 20, n)).astype("<f4")
+    b = (rng.normal(size=n) * 10.0 ** rng.uniform(-20, 20, n)).astype("<f4")
+    c = (rng.normal(size=n) * 10.0 ** rng.uniform(-20, 20, n)).astype("<f4")
+    # include denormals, zeros and infinities
+    a[:8] = [0.0, -0.0, 1e-42, -1e-42, np.inf, 1.0, 3.0, 1e-38]
+    b[:8] = [1.0, 2.0, 3.0, 1e-3, 2.0, 3.0, 1e-42, 1e-7]
+    assert np.array_equal(pt.math_selftest(a, b, c).view("<u4"), po.math_selftest(a, b, c).view("<u4"))
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_golden_ray_sets(pt, config_scenes, cfg):
+    arrays, _ = config_scenes(cfg)
+    pt.upload_scene(arrays)
+    for bounce in (0, 1):
+        rays = np.ascontiguousarray(GOLD[f"cfg{cfg}_bounce{bounce}_rays"]).view(ffi.Ray).reshape(-1)
+        want = np.ascontiguousarray(GOLD[f"cfg{cfg}_bounce{bounce}_hits"]).view(ffi.HitId).reshape(-1)
+        assert hits_equal(pt.trace_closest(rays), want)
+
+
+@pytest.mark.parametrize("scene_name", ["cfg1", "cfg2", "knot", "cfg4_small"])
+def test_closest_and_any_hit_ids_and_visit_counts(pt, config_scenes, small_knot_scene, scene_name):
+    if scene_name == "knot":
+        arrays = small_knot_scene
+        centre = (0.0, 0.0, 3.0)
+    elif scene_name == "cfg4_small":
+        arrays, _ = config_scenes(4, dragon_n_u=48, dragon_n_v=12)  # 1000 instances, small dragon stand-in
+        centre = (0.0, 0.0, 14.0)
+    else:
+        arrays, _ = config_scenes(int(scene_name[3:]))
+        centre = (0.0, 0.0, 3.0)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    rays = random_rays(100003, 21, centre=centre, spread=2.0 if scene_name != "cfg4_small" else 10.0)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want)
+    assert gc.as_dict() == wc.as_dict()
+    assert (want["instance_id"] != ffi.NO_HIT).sum() > 1000
+    # exclusion of the primitive just hit, as the bounce rays use it
+    hit = want["instance_id"] != ffi.NO_HIT
+    again = rays.copy()
+    again["last_inst"] = np.where(hit, want["instance_id"], ffi.NO_PRIM)
+    again["last_prim"] = np.where(hit, want["triangle_id"], ffi.NO_PRIM)
+    assert hits_equal(pt.trace_closest(again), sc.trace_closest(again))
+    # shadow / connect query: first accepted triangle in traversal order
+    tmax = np.random.default_rng(3).uniform(0.2, 8.0, len(rays)).astype("<f4")
+    wany, wac = sc.trace_any(rays, tmax, True)
+    gany, gac = pt.trace_any(rays, tmax, True)
+    assert hits_equal(gany, wany)
+    assert gac.as_dict() == wac.as_dict()
+
+
+def test_empty_and_ragged_ray_sets(pt, config_scenes):
+    arrays, _ = config_scenes(1)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    assert len(pt.trace_closest(np.zeros(0, ffi.Ray))) == 0
+    for n in (1, 63, 64, 65, 257):
+        rays = random_rays(n, n)
+        assert hits_equal(pt.trace_closest(rays), sc.trace_closest(rays))
+    # axis-parallel rays (zero direction components -> infinities in the slab test)
+    rays = random_rays(512, 77)
+    rays["dir"] = 0.0
+    rays["dir"][:, 2] = 1.0
+    rays["dir"][::2, 2] = -1.0
+    rays["pos"][:, 2] = np.where(rays["dir"][:, 2] > 0, -1.0, 8.0)
+    assert hits_equal(pt.trace_closest(rays), sc.trace_closest(rays))
+
+
+@pytest.mark.parametrize("cfg,W,H,spp", [(1, 64, 64, 2), (2, 64, 36, 1)])
+def test_golden_render_sums(pt, config_scenes, cfg, W, H, spp):
+    arrays, info = config_scenes(cfg)
+    pt.upload_scene(arrays)
+    src = host.make_sample_sources(W, H, info.seed)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    pt.create_state(W, H, 1000, src, prm)  # far fewer slots than samples: slots are recycled
+    pt.set_camera(host.default_camera(W, H))
+    pt.stats_reset()
+    pt.render_spp(spp)
+    s4, cnt = pt.read_accum()
+    assert np.array_equal(s4, GOLD[f"cfg{cfg}_mode0_sum4"])
+    assert np.array_equal(cnt, GOLD[f"cfg{cfg}_mode0_count"])
+    st = pt.stats()
+    assert [st.extend_rays, st.connect_rays, st.shade_events] == GOLD[f"cfg{cfg}_mode0_rays"].tolist()
+    assert st.finished_samples == W * H * spp == st.spawned_samples
+
+
+def test_config1_full_render_and_pixels(pt, config_scenes):
+    # configuration 1 in full: suzanne + light, 256x256, 1 spp, 4 bounces
+    arrays, info = config_scenes(1)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    W, H = info.width, info.height
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    pt.create_state(W, H, W * H, src, prm)
+    pt.set_camera(cam)
+    pt.set_counting(True)
+    pt.stats_reset()
+    pt.render_spp(info.spp)
+    pt.set_counting(False)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, wst = sc.render(cam, src, W, H, oprm, 0, info.spp)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+    assert np.array_equal(pt.read_output(), po.resolve(w4, wcnt, src, W, H, oprm))
+    st = pt.stats()
+    assert st.extend_counts.as_dict() == wst.extend_counts.as_dict()
+    # a second call continues with the next sample numbers
+    pt.render_spp(2)
+    s4b, cntb = pt.read_accum()
+    sc.render(cam, src, W, H, oprm, info.spp, 2, sum4=w4, count=wcnt)
+    assert np.array_equal(s4b, w4) and np.array_equal(cntb, wcnt)
+
+
+def test_render_with_cooperative_leaves_and_many_bounces(pt, small_knot_scene):
+    arrays = small_knot_scene
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    W, H = 160, 90
+    src = host.make_sample_sources(W, H, 5)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=8, seed=77)
+    oprm = po.default_params(max_bounces=8, seed=77)
+    pt.create_state(W, H, 4096, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(2)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, _ = sc.render(cam, src, W, H, oprm, 0, 2)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+
+
+def test_bounce_rays_dumped_from_the_device_match_the_oracle(pt, config_scenes):
+    arrays, info = config_scenes(2)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    W, H = 96, 54
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=8, seed=info.seed)
+    oprm = po.default_params(max_bounces=8, seed=info.seed)
+    pt.create_state(W, H, W * H, src, prm)  # one slot per source
+    pt.set_camera(cam)
+    pt.step(2)
+    pt.synchronize()
+    got = pt.dump_extension_rays(W * H)
+    # After two frames the extension queue holds what the second shade launch
+    # pushed: the bounce-2 rays of sample 0 of every source, plus the bounce-1
+    # rays of the samples respawned in frame 1 — sample 1 of sources 0..n1-1,
+    # where n1 slots were freed by sample-0 paths that missed everything.
+    b2 = sc.bounce_rays(cam, src, W, H, oprm, 0, 2)
+    b2 = b2[b2["last_inst"] != ffi.NO_HIT]
+    b1_k0 = sc.bounce_rays(cam, src, W, H, oprm, 0, 1)
+    n1 = int((b1_k0["last_inst"] == ffi.NO_HIT).sum())
+    b1 = sc.bounce_rays(cam, src[:n1].copy(), W, H, oprm, 1, 1)
+    b1 = b1[b1["last_inst"] != ffi.NO_HIT]
+    want = np.concatenate([b2, b1])
+    assert len(got) == len(want) > 100
+
+    def key(r):
+        return np.sort(r.view("<u4").reshape(-1, 8).view([("k", "<u4", 8)]).reshape(-1), order="k")
+
+    assert np.array_equal(key(got), key(want))  # queue order is free, the set is not
+
+
+def test_errors_are_reported_not_thrown(pt, config_scenes):
+    arrays, _ = config_scenes(1)
+    bad = {k: v.copy() for k, v in arrays.items()}
+    bad["blas_nodes"]["right"][3] = 10 ** 6
+    with pytest.raises(pathtracer.MirtError, match="skip link"):
+        pt.upload_scene(bad)
+    bad = {k: v.copy() for k, v in arrays.items()}
+    bad["blas_nodes"]["right"][1] = 1  # a skip link onto itself: the walk would never end
+    with pytest.raises(pathtracer.MirtError, match="cycle"):
+        pt.upload_scene(bad)
+    bad = {k: v.copy() for k, v in arrays.items()}
+    bad["instances"]["material"][0] = 7
+    with pytest.raises(pathtracer.MirtError):
+        pt.upload_scene(bad)
+    fresh = pathtracer.Pathtracer(0)
+    with pytest.raises(pathtracer.MirtError, match="no scene"):
+        fresh.trace_closest(random_rays(4, 1))
+    fresh.upload_scene(arrays)
+    with pytest.raises(pathtracer.MirtError, match="state"):
+        fresh.render_spp(1)
+    src = host.make_sample_sources(8, 8, 1)
+    src["out_pos"][0] = (99, 0)
+    with pytest.raises(pathtracer.MirtError, match="outside"):
+        fresh.create_state(8, 8, 64, src, pathtracer.default_params())
+    fresh.close()
+    L = ffi.device_lib()
+    assert L.mirt_create(10 ** 6, ffi.C.byref(ffi.C.c_void_p())) != 0
+    assert L.mirt_scene_upload(None, None) != 0
+
+
+def test_full_size_properties_config3_1080p(pt, config_scenes):
+    # the benchmark workload at full size: properties that need no oracle run
+    arrays, info = config_scenes(3)
+    pt.upload_scene(arrays)
+    W, H = info.width, info.height
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    pt.create_state(W, H, W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(2)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == 2) and st.finished_samples == 2 * W * H
+    assert st.extend_rays >= st.finished_samples and st.shade_events <= st.extend_rays
+    # every path is either terminated by the sky or runs out of bounces
+    assert st.extend_rays - st.shade_events <= st.finished_samples
+    # sample ranges add up: [0,1) + [1,2) == [0,2), with a different slot count
+    pt.create_state(W, H, 700001, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(1)
+    pt.render_spp(1)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+    # a slice of it against the oracle: the first 4096 sources' sums
+    sc = po.Scene(arrays)
+    oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    w4, wc, _ = sc.render(cam, src[:4096].copy(), W, H, oprm, 0, 2)
+    assert np.array_equal(a4[: 4 * 4096], w4) and np.array_equal(ac[:4096], wc)
+    # sky-only furnace at full size
+    cam2 = cam.copy()
+    cam2["forward"][0] = (0.0, 0.0, -1.0)
+    cam2["changed"] = 1
+    pt.set_camera(cam2)
+    pt.render_spp(1)
+    f4, fc = pt.read_accum()
+    assert np.all(fc == 1) and np.all(f4.reshape(-1, 4)[:, :3] == 10000)
