@@ -47,7 +47,7 @@ $(LIBDIR)/libmirt.a: $(DEV_OBJ)
 	@mkdir -p $(LIBDIR)
 	rm -f $@ && ar rcs $@ $(DEV_OBJ)
 
-oracle/liboracle.so: oracle/oracle.c oracle/oracle.h include/mirt.h
+oracle/liboracle.so: oracle/oracle.c oracle/oracle_classic.inc oracle/oracle.h include/mirt.h
 	$(CC) $(ORACLE_FLAGS) -shared -o $@ oracle/oracle.c -lm
 
 clean:

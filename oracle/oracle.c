@@ -500,6 +500,10 @@ typedef struct {
   v3 ray_pos, ray_dir;
   uint32_t last_inst, last_prim;
   hitrec hit;
+  /* the connect (shadow) ray traced at the latest hit, if any */
+  MirtRay connect_ray;
+  float connect_tmax;
+  int connect_valid;
 } path;
 
 /* spawnSample (shaders/sample.slang:59-102) */
@@ -822,6 +826,34 @@ void oracle_bounce_rays(const oracle_scene *s, const MirtCamera *camera, const M
       r.last_inst = p.last_inst; r.last_prim = p.last_prim;
     } else {
       r.last_inst = NO_HIT; r.last_prim = NO_HIT;
+    }
+    out[i] = r;
+  }
+}
+
+void oracle_connect_rays(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                         uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                         uint32_t sample_no, uint32_t bounce, MirtRay *out, float *tmax_out) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (long i = 0; i < (long)n_sources; ++i) {
+    OracleRenderStats st;
+    memset(&st, 0, sizeof(st));
+    path p;
+    memset(&p, 0, sizeof(p));
+    spawn_sample(&p, camera, &sources[i], (uint32_t)i, sample_no, width, height, params);
+    int alive = 1, advanced = 0;
+    for (uint32_t b = 0; b <= bounce && alive; ++b) {
+      p.connect_valid = 0;
+      alive = advance_path(s, &p, params, &st);
+      advanced = (int)b + 1;
+    }
+    MirtRay r;
+    memset(&r, 0, sizeof(r));
+    r.last_inst = NO_HIT; r.last_prim = NO_HIT;
+    tmax_out[i] = 0.0f;
+    if (advanced == (int)bounce + 1 && p.connect_valid) {
+      r = p.connect_ray;
+      tmax_out[i] = p.connect_tmax;
     }
     out[i] = r;
   }

@@ -72,6 +72,15 @@ void oracle_bounce_rays(const oracle_scene *s, const MirtCamera *camera, const M
                         uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
                         uint32_t sample_no, uint32_t bounce, MirtRay *out);
 
+/* The connect (shadow) ray traced at the hit of bounce `bounce` of sample
+ * `sample_no` of every source (per-material shading with light sampling):
+ * origin, direction, excluded light triangle in last_inst / last_prim, and the
+ * light distance in tmax_out.  out[i].last_inst == 0xFFFFFFFF when no connect
+ * ray is traced there. */
+void oracle_connect_rays(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                         uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                         uint32_t sample_no, uint32_t bounce, MirtRay *out, float *tmax_out);
+
 /* Tone-map means to packed pixels (sample.slang:18-57, common.slang:177-183). */
 void oracle_resolve(const uint32_t *sum4, const uint32_t *count, const MirtSampleSource *sources,
                     uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,

@@ -42,6 +42,7 @@ def lib():
         L.oracle_render_wavefront.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, u32,
                                               vp, vp, C.POINTER(RenderStats), C.POINTER(C.c_uint64)]
         L.oracle_bounce_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp]
+        L.oracle_connect_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp, vp]
         L.oracle_resolve.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), vp]
         L.oracle_math_selftest.argtypes = [vp, vp, vp, sz, vp]
         _lib = L
@@ -137,6 +138,19 @@ class Scene:
         lib().oracle_bounce_rays(self._h, camera.ctypes.data, sources.ctypes.data, len(sources), width, height,
                                  C.byref(params), sample_no, bounce, out.ctypes.data)
         return out
+
+
+def _connect_rays(self, camera, sources, width, height, params, sample_no, bounce):
+    """Connect (shadow) rays traced at the hit of `bounce`: (rays, tmax) of the paths that trace one."""
+    out = np.zeros(len(sources), ffi.Ray)
+    tmax = np.zeros(len(sources), "<f4")
+    lib().oracle_connect_rays(self._h, camera.ctypes.data, sources.ctypes.data, len(sources), width, height,
+                              C.byref(params), sample_no, bounce, out.ctypes.data, tmax.ctypes.data)
+    keep = out["last_inst"] != ffi.NO_HIT
+    return out[keep], tmax[keep]
+
+
+Scene.connect_rays = _connect_rays
 
 
 def resolve(sum4, count, sources, width, height, params):

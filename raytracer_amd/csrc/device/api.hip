@@ -715,10 +715,18 @@ int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
   // counter every few frames; the loop ends when all samples of this call
   // have been accumulated.
   const uint32_t poll = 4;
+  // A sample lives at most max_bounces + 1 frames after its spawn and a slot
+  // respawns in the frame after it terminates; more frames than this bound
+  // means paths were lost, which must end the call rather than spin.
+  const unsigned long long rounds = (limit + ctx->st.slots - 1) / ctx->st.slots + 1;
+  const unsigned long long max_frames = rounds * ((unsigned long long)ctx->params.max_bounces + 2ull) + 8ull;
+  unsigned long long frames = 0;
   while (true) {
     for (uint32_t f = 0; f < poll; ++f) run_frame(ctx, limit, first);
+    frames += poll;
     if ((rc = fetch_counters(ctx)) != MIRT_OK) return rc;
     if (ctx->h_stats[S_FINISHED] - finished0 >= limit) break;
+    if (frames > max_frames) return fail(ctx, MIRT_ERR_HIP, "render_spp: the wavefront did not drain");
   }
   ctx->next_sample = first + spp;
   ctx->slots_seeded = false;

@@ -1,6 +1,319 @@
-// classic.hip — placeholder launchers, replaced below by the per-material kernels.
+// classic.hip — the per-material shading path: the connect (shadow) kernel
+// with light sampling, and one kernel per material kind (Lambertian, Metallic,
+// Dielectric, Emissive), each popping its own queue.
+//
+// Restates shaders/archive/{shadow,light,material,lambertian,metallic,
+// dielectric,emissive}.slang on top of the live traversal.  Deliberate
+// differences from the archive text, each a repair of something that cannot
+// work as written:
+//   - the light face is drawn uniformly from the primitive range of the
+//     light's BLAS root with its three real vertices (archive/light.slang:64-67
+//     adds node.end and broadcasts one scalar to all three vertex ids); the
+//     pdf's area is taken from the transformed edges, and (r1,r2) is folded
+//     back into the triangle when r1+r2 > 1;
+//   - visibility is an any-hit query limited to the light distance that
+//     excludes the sampled light triangle, in place of a closest-hit ray that
+//     is accepted when it ends within 1.0 of the sample
+//     (archive/shadow.slang:100-121); the light's geometric normal replaces
+//     the interpolated normal of that closest hit;
+//   - the dielectric kernel uses the front_face flag stored by the extension
+//     stage (archive/dielectric.slang:66 recomputes it from the already
+//     flipped normal, which always yields "front") and multiplies the
+//     throughput by the albedo (archive/dielectric.slang:91 assigns it).
+#include <float.h>
+
 #include "device_util.h"
+
 namespace mirt {
-void launch_connect(const LaunchCfg &, const DScene &, const DState &, const DFrameParams &) {}
-void launch_shade_classic(const LaunchCfg &, const DScene &, const DState &, const DFrameParams &) {}
+
+namespace {
+
+struct SlotIn {
+  float4 pa, pb;  // radiance+bounces, throughput+source
+  Rng rng;
+  v3 rdir;
+  v3 hpos, hn;  // hit position, normal flipped to face the ray
+  uint32_t inst, ff;
+};
+
+__device__ __forceinline__ void load_slot(const DState &st, uint32_t slot, SlotIn &s) {
+  const float4 *p4 = reinterpret_cast<const float4 *>(st.path + slot);
+  s.pa = p4[0];
+  s.pb = p4[1];
+  s.rng = load_rng(st.path + slot);
+  v3 rpos;
+  uint32_t li, lp;
+  load_ray(st.ray, slot, rpos, s.rdir, li, lp);
+  const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+  const float4 ha = h4[0], hb = h4[1];
+  const uint32_t inst_ff = __float_as_uint(ha.w);
+  s.inst = inst_ff & 0x7FFFFFFFu;
+  s.ff = inst_ff >> 31;
+  s.hpos = V3(ha.x, ha.y, ha.z);
+  const float sgn = s.ff != 0u ? 1.0f : -1.0f;
+  s.hn = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
+}
+
+__device__ __forceinline__ void store_slot(const DState &st, uint32_t slot, const SlotIn &s, v3 new_pos, v3 new_dir) {
+  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+  p4[0] = s.pa;
+  p4[1] = s.pb;
+  store_rng(st.path + slot, s.rng);
+  // origins are offset instead of excluding the primitive just hit
+  store_ray(st.ray, slot, new_pos, new_dir, kNoPrim, kNoPrim);
+}
+
+__device__ __forceinline__ v3 rand_unit_sphere(float a, float b, float c) {
+  return normalize3(V3(1.0f - 2.0f * a, 1.0f - 2.0f * b, 1.0f - 2.0f * c));
+}
+
+// LambertianData::brdf / pdf (archive/lambertian.slang:15-24)
+__device__ __forceinline__ v3 lambert_brdf(v3 albedo, v3 wi, v3 wo, v3 n) {
+  if (dot3(n, wi) <= 0.0f || dot3(n, wo) <= 0.0f) return V3(0.0f, 0.0f, 0.0f);
+  return V3(albedo.x / 3.1415f, albedo.y / 3.1415f, albedo.z / 3.1415f);
+}
+__device__ __forceinline__ float lambert_pdf(v3 wi, v3 n) { return fmax_nn(0.0f, dot3(wi, n)) / 3.1415f; }
+
+// ---------------------------------------------------------------- connect
+// shadowMain (archive/shadow.slang:63-139) + get_light_sample / tri_sample /
+// tri_pdf (archive/light.slang:14-81).  Pops the connect queue, traces the
+// shadow ray as an any-hit query, writes the slot's ShadowData and routes the
+// slot to the queue of its hit material.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFrameParams fp) {
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *cq = st.qdata[Q_CONNECT];
+  const uint32_t count = st.qcount[Q_CONNECT];
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t n_waves = gridDim.x * 4u;
+  LaneCounts lc;
+  unsigned long long traced = 0;
+  for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+    const uint32_t i = base + lane_id();
+    const bool active = i < count;
+    uint32_t slot = 0, kind = 0;
+    bool shoot = false;
+    v3 orig = V3(0.0f, 0.0f, 0.0f), scatter = V3(1.0f, 1.0f, 1.0f), d = V3(0.0f, 0.0f, 0.0f);
+    v3 light_n = V3(0.0f, 0.0f, 1.0f);
+    float shadow_t = 0.0f, sample_prob = 0.0f;
+    uint32_t light_inst = kNoPrim, light_prim = kNoPrim;
+    if (active) {
+      slot = cq[i];
+      const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+      const float4 ha = h4[0], hb = h4[1];
+      const uint32_t inst_ff = __float_as_uint(ha.w);
+      const float sgn = (inst_ff >> 31) != 0u ? 1.0f : -1.0f;
+      const v3 nf = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
+      kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
+      orig = add3(V3(ha.x, ha.y, ha.z), scale3(nf, 1e-3f));
+      Rng rng = load_rng(st.path + slot);
+      // light instance and face (two draws), then a point on the face (two draws)
+      const float r1 = rng_next(rng);
+      const float r2 = rng_next(rng);
+      uint32_t li = (uint32_t)__builtin_floorf(r1 * (float)sc.n_lights);
+      if (li >= sc.n_lights) li = sc.n_lights - 1u;  // r1 can be exactly 1
+      light_inst = sc.lights[li];
+      const DInst *inst = &sc.inst[light_inst];
+      const uint32_t n_faces = inst->root_count;
+      uint32_t fi = (uint32_t)__builtin_floorf(r2 * (float)n_faces);
+      if (fi >= n_faces) fi = n_faces - 1u;
+      light_prim = inst->root_start + fi;
+      const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + light_prim);
+      const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
+      const v3 p0 = V3(a0.x, a0.y, a0.z), e1 = V3(a1.x, a1.y, a1.z), e2 = V3(a2.x, a2.y, a2.z);
+      float a = rng_next(rng);
+      float b = rng_next(rng);
+      if (a + b > 1.0f) {
+        a = 1.0f - a;
+        b = 1.0f - b;
+      }
+      store_rng(st.path + slot, rng);
+      const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
+      const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
+      const float area = 0.5f * length3(cr);
+      const float tri_pdf = area > 0.0f ? 1.0f / area : 1.0f;
+      sample_prob = tri_pdf * (1.0f / (float)(sc.n_lights * n_faces));
+      light_n = normalize3(cr);
+      d = sub3(sample_pos, orig);
+      shadow_t = length3(d);
+      scatter = normalize3(d);
+      shoot = dot3(scatter, nf) > 0.0f;
+      if (shoot) traced++;
+    }
+    float t = shadow_t;
+    BestHit best;
+    const bool occluded = traverse<true, COUNT>(sc, shoot, orig, scatter, light_inst, light_prim, t, best, lc);
+    if (active) {
+      float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (shoot && !occluded) {
+        const DInst *linst = &sc.inst[light_inst];
+        v3 rad = V3(0.0f, 0.0f, 0.0f);
+        if (linst->kind == MIRT_MAT_EMISSIVE) {
+          const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
+          rad = V3(e[0], e[1], e[2]);
+        }
+        const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(scatter)));
+        s0 = make_float4(scatter.x, scatter.y, scatter.z, prob);
+        s1 = make_float4(rad.x, rad.y, rad.z, 0.0f);
+      }
+      float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
+      sh4[0] = s0;
+      sh4[1] = s1;
+    }
+    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], active && kind == MIRT_MAT_LAMBERTIAN, slot);
+    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], active && kind == MIRT_MAT_METALLIC, slot);
+    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], active && kind == MIRT_MAT_DIELECTRIC, slot);
+    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], active && kind == MIRT_MAT_EMISSIVE, slot);
+    // no material (archive/logic.slang:171-174): the path ends here
+    wave_push(&st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && kind == MIRT_MAT_NONE, slot);
+  }
+  if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
+  for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
+  if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
+}
+
+// ------------------------------------------------------- material kernels
+// Common frame of the four kernels: pop `queue`, shade, push to the next
+// frame's extension queue (alive) or terminate queue.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_material(DScene sc, DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  const uint32_t par = fp.frame & 1u;
+  const int q = Q_LAMBERTIAN - 1 + KIND;
+  const uint32_t *mq = st.qdata[q];
+  const uint32_t count = st.qcount[q];
+  const bool use_shadow = fp.p.nee != 0u && fp.have_lights != 0u;
+  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < count;
+    uint32_t slot = 0;
+    bool alive = false;
+    if (active) {
+      slot = mq[i];
+      SlotIn s;
+      load_slot(st, slot, s);
+      const DInst *inst = &sc.inst[s.inst];
+      v3 new_pos = s.hpos, new_dir = s.rdir;
+      v3 thr = V3(s.pb.x, s.pb.y, s.pb.z), rad = V3(s.pa.x, s.pa.y, s.pa.z);
+      if (KIND == MIRT_MAT_LAMBERTIAN) {
+        // process_material<LambertianData> (archive/material.slang:17-139,
+        // archive/lambertian.slang:26-35)
+        const float *ad = sc.lambertian + 4 * (size_t)inst->kind_data;
+        const v3 albedo = V3(ad[0], ad[1], ad[2]);
+        const v3 nf = s.hn;
+        const v3 wo = neg3(s.rdir);
+        // scatter draws three values but stores the state after the second
+        const float a = rng_next(s.rng);
+        const float b = rng_next(s.rng);
+        Rng tmp = s.rng;
+        const float c = rng_next(tmp);
+        const v3 scv = add3(nf, rand_unit_sphere(a, b, c));
+        const v3 wi = normalize3(length3(scv) < 1e-6f ? nf : scv);
+        const float scatter_prob = lambert_pdf(wi, nf);
+        (void)rng_next(s.rng);  // archive/material.slang:91-92
+        alive = true;
+        if (use_shadow) {
+          const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
+          const float4 s0 = sh4[0], s1 = sh4[1];
+          const float sprob = s0.w;
+          if (sprob > 0.0f) {
+            const v3 sdir = V3(s0.x, s0.y, s0.z);
+            float shadow_weight = 1.0f * sprob;
+            shadow_weight /= (1.0f * sprob + 1.0f * lambert_pdf(sdir, nf));
+            v3 contrib = thr;
+            contrib = mul3(contrib, lambert_brdf(albedo, sdir, wo, nf));
+            contrib = scale3(contrib, dot3(sdir, nf));
+            contrib = scale3(contrib, shadow_weight);
+            const float dl = 1.0f * sprob;
+            contrib = V3(contrib.x / dl, contrib.y / dl, contrib.z / dl);
+            rad = add3(rad, mul3(V3(s1.x, s1.y, s1.z), contrib));
+          }
+        }
+        if (scatter_prob > 0.0f) {
+          float scatter_weight = 1.0f * scatter_prob;
+          scatter_weight /= 1.0f * scatter_prob + 1.0f * 0.0f;
+          thr = mul3(thr, lambert_brdf(albedo, wi, wo, nf));
+          thr = scale3(thr, dot3(wi, nf));
+          thr = scale3(thr, scatter_weight);
+          const float ds = 1.0f * scatter_prob;
+          thr = V3(thr.x / ds, thr.y / ds, thr.z / ds);
+        } else {
+          thr = scale3(thr, 0.0f);
+          alive = false;
+        }
+        new_pos = add3(s.hpos, scale3(nf, 1e-3f));
+        new_dir = wi;
+      } else if (KIND == MIRT_MAT_METALLIC) {
+        // archive/metallic.slang:65-96
+        const float *md = sc.metallic + 8 * (size_t)inst->kind_data;
+        const v3 nf = s.hn;
+        new_pos = add3(s.hpos, scale3(nf, 0.005f));
+        thr = mul3(thr, V3(md[0], md[1], md[2]));
+        const v3 dir = s.rdir;
+        const v3 reflected = sub3(dir, scale3(nf, 2.0f * dot3(dir, nf)));
+        const float a = rng_next(s.rng), b = rng_next(s.rng), c = rng_next(s.rng);
+        const v3 scv = add3(reflected, scale3(rand_unit_sphere(a, b, c), md[4]));
+        new_dir = normalize3(length3(scv) < 1e-2f ? reflected : scv);
+        alive = true;
+      } else if (KIND == MIRT_MAT_DIELECTRIC) {
+        // archive/dielectric.slang:34-95
+        const float *dd = sc.dielectric + 8 * (size_t)inst->kind_data;
+        const v3 nf = s.hn;
+        const float ir = dd[4];
+        const float ratio = s.ff != 0u ? (1.0f / ir) : ir;
+        const v3 ud = normalize3(s.rdir);
+        const float cos_theta = fmin_nn(-dot3(ud, nf), 1.0f);
+        const float sin_theta = __builtin_sqrtf(fmax_nn(0.0f, 1.0f - pow2f(cos_theta)));
+        const bool cannot_refract = ratio * sin_theta > 1.0f;
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 *= r0;
+        const float reflectance = r0 + (1.0f - r0) * pow5f(1.0f - cos_theta);
+        const float rnd = rng_next(s.rng);
+        v3 scv;
+        if (cannot_refract || reflectance > rnd) {
+          scv = sub3(ud, scale3(nf, 2.0f * dot3(ud, nf)));
+          new_pos = add3(s.hpos, scale3(nf, 1e-4f));
+        } else {
+          const float ct = fmin_nn(-dot3(ud, nf), 1.0f);
+          const v3 perp = scale3(add3(ud, scale3(nf, ct)), ratio);
+          const float k = 1.0f - dot3(perp, perp);
+          const v3 par_v = scale3(nf, -__builtin_sqrtf(fmax_nn(k, 0.0f)));
+          scv = add3(perp, par_v);
+          new_pos = sub3(s.hpos, scale3(nf, 1e-4f));
+        }
+        thr = mul3(thr, V3(dd[0], dd[1], dd[2]));
+        new_dir = normalize3(scv);
+        alive = true;
+      } else {
+        // archive/emissive.slang:42-59
+        const float *ed = sc.emissive + 4 * (size_t)inst->kind_data;
+        rad = add3(rad, mul3(V3(ed[0], ed[1], ed[2]), thr));
+        alive = false;
+      }
+      s.pa.x = rad.x; s.pa.y = rad.y; s.pa.z = rad.z;
+      s.pb.x = thr.x; s.pb.y = thr.y; s.pb.z = thr.z;
+      store_slot(st, slot, s, new_pos, new_dir);
+    }
+    block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
+                &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)count);
+}
+
+}  // namespace
+
+void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  if (fp.counting) hipLaunchKernelGGL((k_connect<true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_connect<false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+}
+
+void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  // the four per-material kernels, one queue each (archive frame order:
+  // src/app.rs:402-410 dispatches every material phase each frame)
+  hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+}
+
 }  // namespace mirt

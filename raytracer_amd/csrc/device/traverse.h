@@ -29,7 +29,10 @@
 
 namespace mirt {
 
-constexpr uint32_t kCoopLeaf = 24u;
+#ifndef MIRT_COOP_LEAF
+#define MIRT_COOP_LEAF 24u
+#endif
+constexpr uint32_t kCoopLeaf = MIRT_COOP_LEAF;
 
 struct LaneCounts {
   uint32_t tlas_nodes = 0, instance_visits = 0, blas_nodes = 0, triangles = 0;

@@ -221,7 +221,8 @@ def device_lib():
     """libmirt.so — HIP kernels + C ABI.  Required: there is no CPU fallback."""
     global _device
     if _device is None:
-        L = _load("libmirt.so")
+        # MIRT_DEVICE_LIB selects another build of the same library (A/B experiments)
+        L = _load(os.environ.get("MIRT_DEVICE_LIB", "libmirt.so"))
         vp, i32, u32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
         for s in DEVICE_SYMBOLS:
             getattr(L, s)  # raises AttributeError if the ABI is incomplete

@@ -101,21 +101,56 @@ def test_empty_and_ragged_ray_sets(pt, config_scenes):
 
 
 @pytest.mark.parametrize("cfg,W,H,spp", [(1, 64, 64, 2), (2, 64, 36, 1)])
-def test_golden_render_sums(pt, config_scenes, cfg, W, H, spp):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_render_sums(pt, config_scenes, cfg, W, H, spp, mode):
+    # mode 0: uber shading (shade.slang); mode 1: per-material kernels + connect rays
     arrays, info = config_scenes(cfg)
     pt.upload_scene(arrays)
     src = host.make_sample_sources(W, H, info.seed)
-    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=mode, nee=mode)
     pt.create_state(W, H, 1000, src, prm)  # far fewer slots than samples: slots are recycled
     pt.set_camera(host.default_camera(W, H))
     pt.stats_reset()
     pt.render_spp(spp)
     s4, cnt = pt.read_accum()
-    assert np.array_equal(s4, GOLD[f"cfg{cfg}_mode0_sum4"])
-    assert np.array_equal(cnt, GOLD[f"cfg{cfg}_mode0_count"])
+    assert np.array_equal(s4, GOLD[f"cfg{cfg}_mode{mode}_sum4"])
+    assert np.array_equal(cnt, GOLD[f"cfg{cfg}_mode{mode}_count"])
     st = pt.stats()
-    assert [st.extend_rays, st.connect_rays, st.shade_events] == GOLD[f"cfg{cfg}_mode0_rays"].tolist()
+    assert [st.extend_rays, st.connect_rays, st.shade_events] == GOLD[f"cfg{cfg}_mode{mode}_rays"].tolist()
     assert st.finished_samples == W * H * spp == st.spawned_samples
+
+
+def test_per_material_kernels_and_connect_rays_config5_small(pt, config_scenes):
+    # configuration 5's scene (Cornell box with ceiling light + dielectric dragon
+    # stand-in), per-material shading with light sampling, against the oracle
+    arrays, info = config_scenes(5, dragon_n_u=96, dragon_n_v=24)
+    assert info.shade_mode == 1 and info.nee == 1
+    kinds = sorted(set(arrays["classic_refs"]["kind"].tolist()))
+    assert kinds == [ffi.MAT_LAMBERTIAN, ffi.MAT_DIELECTRIC, ffi.MAT_EMISSIVE]
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    W, H = 192, 108
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=8, seed=info.seed, shade_mode=1, nee=1)
+    oprm = po.default_params(max_bounces=8, seed=info.seed, shade_mode=1, nee=1)
+    pt.create_state(W, H, 5000, src, prm)
+    pt.set_camera(cam)
+    pt.set_counting(True)
+    pt.stats_reset()
+    pt.render_spp(3)
+    pt.set_counting(False)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, wst = sc.render(cam, src, W, H, oprm, 0, 3)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+    st = pt.stats()
+    assert (st.extend_rays, st.connect_rays, st.shade_events) == (wst.extend_rays, wst.connect_rays, wst.shade_events)
+    assert st.connect_rays > 1000
+    assert st.extend_counts.as_dict() == wst.extend_counts.as_dict()
+    assert st.connect_counts.as_dict() == wst.connect_counts.as_dict()
+    # the metallic kernel too (configuration 2 carries a metallic teapot)
+    arrays2, info2 = config_scenes(2)
+    assert ffi.MAT_METALLIC in arrays2["classic_refs"]["kind"].tolist()
 
 
 def test_config1_full_render_and_pixels(pt, config_scenes):
