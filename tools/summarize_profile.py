@@ -4,12 +4,11 @@ import csv, glob, os, sys, collections
 
 out = sys.argv[1]
 
+import re
+
 def short(n):
-    n = n.split("(")[0]
-    for k in ("k_extend", "k_shade_uber", "k_sample", "k_trace", "k_resolve", "k_init_slots", "k_connect", "k_shade_"):
-        if k in n:
-            return n[n.index(k):].split("ENS")[0][:40]
-    return n[:60]
+    m = re.search(r"(k_\w+(<[^>]*>)?)", n)
+    return m.group(1) if m else n[:60]
 
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     print("== kernel stats:", os.path.relpath(f, out))
