@@ -234,6 +234,11 @@ typedef struct MirtStats {
   uint64_t sample_launches;   double sample_ms;
   MirtTraversalCounts extend_counts;  /* filled only when counting is enabled */
   MirtTraversalCounts connect_counts;
+  /* diagnostic builds only (-DMIRT_PHASE_TIMING): shader-clock cycles summed over
+   * waves of the extend kernel: refill, node phase, small-leaf phase, wave-wide
+   * leaf phase, whole kernel; then node-phase iterations, wave-wide leaf
+   * iterations, engine rounds. */
+  uint64_t engine_phase[8];
 } MirtStats;
 
 typedef struct mirt_ctx mirt_ctx;

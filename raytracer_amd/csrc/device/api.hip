@@ -296,6 +296,7 @@ LaunchCfg launch_cfg(mirt_ctx *c) {
   uint32_t want = c->have_state ? (c->st.slots + 255u) / 256u : 1u;
   uint32_t cap = (uint32_t)c->num_cus * 8u;
   cfg.grid_blocks = (int)(want < cap ? (want ? want : 1u) : cap);
+  cfg.num_cus = c->num_cus;
   return cfg;
 }
 
@@ -429,7 +430,7 @@ int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
     c->num_cus = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MIRT_ERR_HIP; }
   if (hipHostMalloc((void **)&c->h_stats, (S_COUNT + Q_COUNT) * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
-      hipMalloc((void **)&c->d_trace_counts, 5 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void **)&c->d_trace_counts, 6 * sizeof(unsigned long long)) != hipSuccess) {
     (void)hipStreamDestroy(c->stream);
     delete c;
     return MIRT_ERR_OUT_OF_MEMORY;
@@ -629,7 +630,7 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if ((rc = dev_alloc(ctx, own, &st.shadow, threads)) != MIRT_OK) return rc;
   for (int q = 0; q < Q_COUNT; ++q)
     if ((rc = dev_alloc(ctx, own, &st.qdata[q], threads)) != MIRT_OK) return rc;
-  if ((rc = dev_alloc(ctx, own, &st.qcount, Q_COUNT)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.qcount, QW_COUNT)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.stats, S_COUNT)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.sample_index, 1)) != MIRT_OK) return rc;
   MirtSampleSource *dsrc = nullptr;
@@ -643,7 +644,7 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   HIP_TRY(ctx, hipMemset(st.count, 0, (size_t)4 * n_sources));
   HIP_TRY(ctx, hipMemset(st.output, 0, (size_t)4 * width * height));
   HIP_TRY(ctx, hipMemset(st.stats, 0, S_COUNT * sizeof(unsigned long long)));
-  HIP_TRY(ctx, hipMemset(st.qcount, 0, Q_COUNT * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemset(st.qcount, 0, QW_COUNT * sizeof(uint32_t)));
   HIP_TRY(ctx, hipMemset(st.sample_index, 0, sizeof(unsigned long long)));
   ctx->st = st;
   ctx->params = *params;
@@ -792,6 +793,9 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
   for (size_t i = 0; i < n; ++i)
     if (rays[i].last_inst != 0x7FFFFFFFu && rays[i].last_inst >= ctx->n_instances && rays[i].last_inst != 0xFFFFFFFFu)
       return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: last_inst out of range");
+  if (any_hit)
+    for (size_t i = 0; i < n; ++i)
+      if (!(tmax[i] >= 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace_any: tmax must be >= 0");
   std::vector<void *> tmp;
   DRay *d_rays = nullptr;
   float *d_tmax = nullptr;
@@ -802,27 +806,35 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
   if (any_hit && (rc = dev_alloc(ctx, tmp, &d_tmax, n)) != MIRT_OK) { free_all(tmp); return rc; }
   hipError_t e = hipMemcpy(d_rays, rays, n * sizeof(MirtRay), hipMemcpyHostToDevice);
   if (e == hipSuccess && any_hit) e = hipMemcpy(d_tmax, tmax, n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_trace_counts, 0, 5 * sizeof(unsigned long long), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ctx->d_trace_counts, 0, 6 * sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) { free_all(tmp); return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e)); }
   LaunchCfg cfg;
   cfg.stream = ctx->stream;
   cfg.grid_blocks = ctx->num_cus * 8;
+  cfg.num_cus = ctx->num_cus;
+  uint32_t *work = reinterpret_cast<uint32_t *>(ctx->d_trace_counts + 5);  // chunk cursor, zeroed before every launch
   if (ms_per_launch) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, false);  // warm-up
-    (void)hipEventRecord(a, ctx->stream);
-    for (uint32_t r = 0; r < repeats; ++r) launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, false);
-    (void)hipEventRecord(b, ctx->stream);
+    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, work, any_hit, false);  // warm-up
+    float total_ms = 0.0f;
+    for (uint32_t r = 0; r < repeats; ++r) {
+      (void)hipMemsetAsync(work, 0, sizeof(uint32_t), ctx->stream);
+      (void)hipEventRecord(a, ctx->stream);
+      launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, work, any_hit, false);
+      (void)hipEventRecord(b, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+      float one = 0.0f;
+      (void)hipEventElapsedTime(&one, a, b);
+      total_ms += one;
+    }
     e = hipStreamSynchronize(ctx->stream);
-    float ms = 0.0f;
-    (void)hipEventElapsedTime(&ms, a, b);
-    *ms_per_launch = repeats ? (double)ms / repeats : 0.0;
+    *ms_per_launch = repeats ? (double)total_ms / repeats : 0.0;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   } else {
-    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, any_hit, counts != nullptr);
+    launch_trace(cfg, ctx->sc, d_rays, d_tmax, n, d_out, ctx->d_trace_counts, work, any_hit, counts != nullptr);
     e = hipStreamSynchronize(ctx->stream);
   }
   if (e == hipSuccess) e = hipGetLastError();
@@ -878,6 +890,7 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
     out->connect_counts.instance_visits = s[S_CON_INST];
     out->connect_counts.blas_nodes = s[S_CON_BLAS];
     out->connect_counts.triangles = s[S_CON_TRI];
+    for (int k = 0; k < 8; ++k) out->engine_phase[k] = s[S_PHASE0 + k];
   }
   out->frames = ctx->frames_total;
   out->extend_launches = ctx->kernel_launches[K_EXTEND];   out->extend_ms = ctx->kernel_ms[K_EXTEND];

@@ -84,89 +84,95 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
   const uint32_t par = fp.frame & 1u;
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
-  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-  const uint32_t n_waves = gridDim.x * 4u;
   LaneCounts lc;
   unsigned long long traced = 0;
-  for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
-    const uint32_t i = base + lane_id();
-    const bool active = i < count;
-    uint32_t slot = 0, kind = 0;
-    bool shoot = false;
-    v3 orig = V3(0.0f, 0.0f, 0.0f), scatter = V3(1.0f, 1.0f, 1.0f), d = V3(0.0f, 0.0f, 0.0f);
-    v3 light_n = V3(0.0f, 0.0f, 1.0f);
-    float shadow_t = 0.0f, sample_prob = 0.0f;
-    uint32_t light_inst = kNoPrim, light_prim = kNoPrim;
-    if (active) {
-      slot = cq[i];
-      const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
-      const float4 ha = h4[0], hb = h4[1];
-      const uint32_t inst_ff = __float_as_uint(ha.w);
-      const float sgn = (inst_ff >> 31) != 0u ? 1.0f : -1.0f;
-      const v3 nf = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
-      kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
-      orig = add3(V3(ha.x, ha.y, ha.z), scale3(nf, 1e-3f));
-      Rng rng = load_rng(st.path + slot);
-      // light instance and face (two draws), then a point on the face (two draws)
-      const float r1 = rng_next(rng);
-      const float r2 = rng_next(rng);
-      uint32_t li = (uint32_t)__builtin_floorf(r1 * (float)sc.n_lights);
-      if (li >= sc.n_lights) li = sc.n_lights - 1u;  // r1 can be exactly 1
-      light_inst = sc.lights[li];
-      const DInst *inst = &sc.inst[light_inst];
-      const uint32_t n_faces = inst->root_count;
-      uint32_t fi = (uint32_t)__builtin_floorf(r2 * (float)n_faces);
-      if (fi >= n_faces) fi = n_faces - 1u;
-      light_prim = inst->root_start + fi;
-      const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + light_prim);
-      const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
-      const v3 p0 = V3(a0.x, a0.y, a0.z), e1 = V3(a1.x, a1.y, a1.z), e2 = V3(a2.x, a2.y, a2.z);
-      float a = rng_next(rng);
-      float b = rng_next(rng);
-      if (a + b > 1.0f) {
-        a = 1.0f - a;
-        b = 1.0f - b;
-      }
-      store_rng(st.path + slot, rng);
-      const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
-      const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
-      const float area = 0.5f * length3(cr);
-      const float tri_pdf = area > 0.0f ? 1.0f / area : 1.0f;
-      sample_prob = tri_pdf * (1.0f / (float)(sc.n_lights * n_faces));
-      light_n = normalize3(cr);
-      d = sub3(sample_pos, orig);
-      shadow_t = length3(d);
-      scatter = normalize3(d);
-      shoot = dot3(scatter, nf) > 0.0f;
-      if (shoot) traced++;
+
+  // Light sampling happens when the slot is fetched.  A slot whose sample lies
+  // behind its surface traces nothing: it gets a ray that cannot hit anything
+  // (tmax < 0 rejects the TLAS root) and is not counted.
+  auto fetch = [&](uint32_t idx, RayIn &r) {
+    const uint32_t slot = cq[idx];
+    const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+    const float4 ha = h4[0], hb = h4[1];
+    const uint32_t inst_ff = __float_as_uint(ha.w);
+    const float sgn = (inst_ff >> 31) != 0u ? 1.0f : -1.0f;
+    const v3 nf = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
+    const v3 orig = add3(V3(ha.x, ha.y, ha.z), scale3(nf, 1e-3f));
+    Rng rng = load_rng(st.path + slot);
+    // light instance and face (two draws), then a point on the face (two draws)
+    const float r1 = rng_next(rng);
+    const float r2 = rng_next(rng);
+    uint32_t li = (uint32_t)__builtin_floorf(r1 * (float)sc.n_lights);
+    if (li >= sc.n_lights) li = sc.n_lights - 1u;  // r1 can be exactly 1
+    const uint32_t light_inst = sc.lights[li];
+    const DInst *inst = &sc.inst[light_inst];
+    const uint32_t n_faces = inst->root_count;
+    uint32_t fi = (uint32_t)__builtin_floorf(r2 * (float)n_faces);
+    if (fi >= n_faces) fi = n_faces - 1u;
+    const uint32_t light_prim = inst->root_start + fi;
+    const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + light_prim);
+    const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
+    const v3 p0 = V3(a0.x, a0.y, a0.z), e1 = V3(a1.x, a1.y, a1.z), e2 = V3(a2.x, a2.y, a2.z);
+    float a = rng_next(rng);
+    float b = rng_next(rng);
+    if (a + b > 1.0f) {
+      a = 1.0f - a;
+      b = 1.0f - b;
     }
-    float t = shadow_t;
-    BestHit best;
-    const bool occluded = traverse<true, COUNT>(sc, shoot, orig, scatter, light_inst, light_prim, t, best, lc);
-    if (active) {
-      float4 s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (shoot && !occluded) {
+    store_rng(st.path + slot, rng);
+    const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
+    const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
+    const float area = 0.5f * length3(cr);
+    const float tri_pdf = area > 0.0f ? 1.0f / area : 1.0f;
+    const float sample_prob = tri_pdf * (1.0f / (float)(sc.n_lights * n_faces));
+    const v3 light_n = normalize3(cr);
+    const v3 d = sub3(sample_pos, orig);
+    const float shadow_t = length3(d);
+    const v3 scatter = normalize3(d);
+    const bool shoot = dot3(scatter, nf) > 0.0f;
+    // what the epilogue needs is parked in the slot's ShadowData
+    float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
+    const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(scatter)));
+    sh4[0] = make_float4(scatter.x, scatter.y, scatter.z, shoot ? prob : 0.0f);
+    sh4[1] = make_float4(__uint_as_float(light_inst), 0.0f, 0.0f, 0.0f);
+    r.pos = orig;
+    r.dir = scatter;
+    r.last_inst = light_inst;
+    r.last_prim = light_prim;
+    r.tmax = shoot ? shadow_t : -1.0f;
+    r.payload = slot;
+    if (shoot) traced++;
+  };
+  auto finish = [&](bool fin, const RayIn &r, bool occluded, float, const BestHit &) {
+    const uint32_t slot = r.payload;
+    uint32_t kind = 0xFFFFFFFFu;
+    if (fin) {
+      float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
+      float4 s0 = sh4[0];
+      const uint32_t light_inst = __float_as_uint(sh4[1].x);
+      float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (r.tmax >= 0.0f && !occluded) {
         const DInst *linst = &sc.inst[light_inst];
-        v3 rad = V3(0.0f, 0.0f, 0.0f);
         if (linst->kind == MIRT_MAT_EMISSIVE) {
           const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
-          rad = V3(e[0], e[1], e[2]);
+          s1 = make_float4(e[0], e[1], e[2], 0.0f);
         }
-        const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(scatter)));
-        s0 = make_float4(scatter.x, scatter.y, scatter.z, prob);
-        s1 = make_float4(rad.x, rad.y, rad.z, 0.0f);
+      } else {
+        s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
-      float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
       sh4[0] = s0;
       sh4[1] = s1;
+      const uint32_t inst_ff = __float_as_uint(reinterpret_cast<const float4 *>(st.hit + slot)[0].w);
+      kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
     }
-    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], active && kind == MIRT_MAT_LAMBERTIAN, slot);
-    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], active && kind == MIRT_MAT_METALLIC, slot);
-    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], active && kind == MIRT_MAT_DIELECTRIC, slot);
-    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], active && kind == MIRT_MAT_EMISSIVE, slot);
+    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], kind == MIRT_MAT_LAMBERTIAN, slot);
+    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], kind == MIRT_MAT_METALLIC, slot);
+    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], kind == MIRT_MAT_DIELECTRIC, slot);
+    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], kind == MIRT_MAT_EMISSIVE, slot);
     // no material (archive/logic.slang:171-174): the path ends here
-    wave_push(&st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && kind == MIRT_MAT_NONE, slot);
-  }
+    wave_push(&st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], kind == MIRT_MAT_NONE, slot);
+  };
+  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
   for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
   if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
@@ -303,8 +309,9 @@ __global__ __launch_bounds__(256) void k_material(DScene sc, DState st, DFramePa
 }  // namespace
 
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  if (fp.counting) hipLaunchKernelGGL((k_connect<true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_connect<false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  const dim3 grid(trace_grid_blocks(cfg.num_cus));
+  if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_connect<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

@@ -3,7 +3,7 @@
 #pragma once
 
 #include "kernels.h"
-#include "traverse.h"
+#include "engine.h"
 
 namespace mirt {
 

@@ -15,14 +15,19 @@ namespace mirt {
 // pops the same queue (the reference keeps that invariant too).
 enum QueueId {
   Q_TERM0 = 0, Q_TERM1, Q_EXT0, Q_EXT1, Q_SHADE, Q_CONNECT, Q_LAMBERTIAN, Q_METALLIC, Q_DIELECTRIC, Q_EMISSIVE,
-  Q_COUNT
+  Q_COUNT,
+  // work cursors of the two ray-tracing kernels (chunks handed to waves), kept
+  // in the same counter array and cleared by the sample kernel every frame
+  W_EXTEND = Q_COUNT, W_CONNECT,
+  QW_COUNT
 };
 
 // Device counters kept beside the queue counters.
 enum StatId {
   S_EXTEND_RAYS = 0, S_CONNECT_RAYS, S_SHADE_EVENTS, S_SPAWNED, S_FINISHED,
   S_EXT_TLAS, S_EXT_INST, S_EXT_BLAS, S_EXT_TRI, S_CON_TLAS, S_CON_INST, S_CON_BLAS, S_CON_TRI,
-  S_COUNT
+  S_PHASE0,  // eight words written only by diagnostic builds (-DMIRT_PHASE_TIMING)
+  S_COUNT = S_PHASE0 + 8
 };
 
 struct DState {
@@ -31,7 +36,7 @@ struct DState {
   DPath *path;          // [slots]
   DShadow *shadow;      // [slots] (classic shading)
   uint32_t *qdata[Q_COUNT];  // [slots] each
-  uint32_t *qcount;     // [Q_COUNT]
+  uint32_t *qcount;     // [QW_COUNT]
   unsigned long long *stats;         // [S_COUNT]
   unsigned long long *sample_index;  // next sample to hand out in this render call
   const MirtSampleSource *sources;   // [n_sources]
@@ -53,8 +58,13 @@ struct DFrameParams {
 
 struct LaunchCfg {
   hipStream_t stream;
-  int grid_blocks;  // blocks of 256 threads for the frame kernels
+  int grid_blocks;  // blocks of 256 threads for the streaming frame kernels
+  int num_cus;      // the ray-tracing kernels launch a persistent grid sized from this
 };
+
+// Blocks of 256 threads that fill the device for the closest-hit engine
+// (resident blocks per CU from the occupancy query, times CUs).
+int trace_grid_blocks(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
@@ -64,8 +74,9 @@ void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
 void launch_init_slots(const LaunchCfg &cfg, const DState &st);
 
+// `work` is a zeroed device word (the launch's chunk cursor).
 void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,
-                  MirtHitId *out, unsigned long long *counts5, bool any_hit, bool counting);
+                  MirtHitId *out, unsigned long long *counts5, uint32_t *work, bool any_hit, bool counting);
 void launch_math_selftest(hipStream_t stream, const float *a, const float *b, const float *c, size_t n, float *out6);
 
 }  // namespace mirt

@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
     st.qcount[Q_METALLIC] = 0u;
     st.qcount[Q_DIELECTRIC] = 0u;
     st.qcount[Q_EMISSIVE] = 0u;
+    st.qcount[W_EXTEND] = 0u;
+    st.qcount[W_CONNECT] = 0u;
   }
 }
 
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void k_init_slots(DState st) {
     st.qdata[Q_TERM0][i] = i;
     reinterpret_cast<uint32_t *>(st.path + i)[7] = kNoSample;
   }
-  if (i < Q_COUNT) st.qcount[i] = i == Q_TERM0 ? st.slots : 0u;
+  if (i < QW_COUNT) st.qcount[i] = i == Q_TERM0 ? st.slots : 0u;
 }
 
 // ---------------------------------------------------------------- extend
@@ -155,28 +157,24 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
   const uint32_t count = st.qcount[Q_EXT0 + par];
   uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
   uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
-  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-  const uint32_t n_waves = gridDim.x * 4u;
   LaneCounts lc;
 
-  for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
-    const uint32_t i = base + lane_id();
-    const bool active = i < count;
-    uint32_t slot = 0;
+  auto fetch = [&](uint32_t idx, RayIn &r) {
+    const uint32_t slot = ext[idx];
+    load_ray(st.ray, slot, r.pos, r.dir, r.last_inst, r.last_prim);
+    r.tmax = FLT_MAX;
+    r.payload = slot;
+  };
+  // extensionMain's epilogue (shaders/ray_extend.slang:34-50) for the lanes
+  // whose ray is done; called by the whole wave so the pushes can aggregate
+  auto finish = [&](bool fin, const RayIn &r, bool found, float, const BestHit &best) {
+    const uint32_t slot = r.payload;
+    bool hit = fin && found;
     uint32_t route = 0;  // classic: queue of the hit material
-    v3 pos = V3(0.0f, 0.0f, 0.0f), dir = V3(1.0f, 1.0f, 1.0f);
-    uint32_t last_inst = kNoPrim, last_prim = kNoPrim;
-    if (active) {
-      slot = ext[i];
-      load_ray(st.ray, slot, pos, dir, last_inst, last_prim);
-    }
-    float t = FLT_MAX;
-    BestHit best;
-    bool hit = traverse<false, COUNT>(sc, active, pos, dir, last_inst, last_prim, t, best, lc);
-    if (active) {
+    if (fin) {
       DPath *pp = st.path + slot;
-      if (!hit) {
-        // shaders/ray_extend.slang:34-38: rad += throughput * sky
+      if (!found) {
+        // rad += throughput * sky
         float4 *p4 = reinterpret_cast<float4 *>(pp);
         float4 a = p4[0];
         const float4 b = p4[1];
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
       } else {
         v3 hp, hn;
         uint32_t ff;
-        finish_hit(sc, dir, best, hp, hn, ff);
+        finish_hit(sc, r.dir, best, hp, hn, ff);
         float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
         h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
         h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
         }
       }
     }
-    wave_push(term_cnt, term, active && !hit, slot);
+    wave_push(term_cnt, term, fin && !hit, slot);
     if (!CLASSIC) {
       wave_push(&st.qcount[Q_SHADE], st.qdata[Q_SHADE], hit, slot);
     } else {
@@ -219,7 +217,8 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
       wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
       wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
     }
-  }
+  };
+  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
 }
@@ -407,39 +406,31 @@ __global__ __launch_bounds__(256) void k_resolve(DState st, DFrameParams fp) {
 
 template <bool ANY, bool COUNT>
 __global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
-                                               MirtHitId *out, unsigned long long *counts5) {
-  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-  const uint32_t n_waves = gridDim.x * 4u;
+                                               MirtHitId *out, unsigned long long *counts5, uint32_t *work) {
   LaneCounts lc;
-  for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
-    const uint32_t i = base + lane_id();
-    const bool active = i < n;
-    v3 pos = V3(0.0f, 0.0f, 0.0f), dir = V3(1.0f, 1.0f, 1.0f);
-    uint32_t last_inst = kNoPrim, last_prim = kNoPrim;
-    float t = FLT_MAX;
-    if (active) {
-      load_ray(rays, i, pos, dir, last_inst, last_prim);
-      if (ANY) t = tmax[i];
-    }
-    BestHit best;
-    const bool any_found = traverse<ANY, COUNT>(sc, active, pos, dir, last_inst, last_prim, t, best, lc);
-    if (active) {
-      MirtHitId o{0xFFFFFFFFu, 0xFFFFFFFFu, FLT_MAX, 0u};
-      if (any_found) {
-        o.instance_id = best.inst;
-        o.triangle_id = best.prim;
-        o.t = t;
-        if (!ANY) {
-          v3 hp, hn;
-          uint32_t ff;
-          finish_hit(sc, dir, best, hp, hn, ff);
-          o.front_face = ff;
-        }
+  auto fetch = [&](uint32_t idx, RayIn &r) {
+    load_ray(rays, idx, r.pos, r.dir, r.last_inst, r.last_prim);
+    r.tmax = ANY ? tmax[idx] : FLT_MAX;
+    r.payload = idx;
+  };
+  auto finish = [&](bool fin, const RayIn &r, bool found, float t, const BestHit &best) {
+    if (!fin) return;
+    MirtHitId o{0xFFFFFFFFu, 0xFFFFFFFFu, FLT_MAX, 0u};
+    if (found) {
+      o.instance_id = best.inst;
+      o.triangle_id = best.prim;
+      o.t = t;
+      if (!ANY) {
+        v3 hp, hn;
+        uint32_t ff;
+        finish_hit(sc, r.dir, best, hp, hn, ff);
+        o.front_face = ff;
       }
-      reinterpret_cast<float4 *>(out)[i] =
-          make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
     }
-  }
+    reinterpret_cast<float4 *>(out)[r.payload] =
+        make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
+  };
+  trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(counts5, 1, lc);
   if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counts5[0], (unsigned long long)n);
 }
@@ -460,7 +451,7 @@ __global__ void k_math_selftest(const float *a, const float *b, const float *c, 
 // --------------------------------------------------------------- launchers
 
 void launch_init_slots(const LaunchCfg &cfg, const DState &st) {
-  const uint32_t n = st.slots > (uint32_t)Q_COUNT ? st.slots : (uint32_t)Q_COUNT;
+  const uint32_t n = st.slots > (uint32_t)QW_COUNT ? st.slots : (uint32_t)QW_COUNT;
   hipLaunchKernelGGL(k_init_slots, dim3((n + 255u) / 256u), dim3(256), 0, cfg.stream, st);
 }
 
@@ -468,14 +459,25 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
   hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, st, fp);
 }
 
+int trace_grid_blocks(int num_cus) {
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false, false>, 256, 0) != hipSuccess || n < 1) n = 4;
+    per_cu = n > 8 ? 8 : n;
+  }
+  return per_cu * num_cus;
+}
+
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const bool classic = fp.p.shade_mode == MIRT_SHADE_CLASSIC;
+  const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (classic) {
-    if (fp.counting) hipLaunchKernelGGL((k_extend<true, true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend<true, false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+    if (fp.counting) hipLaunchKernelGGL((k_extend<true, true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend<true, false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
   } else {
-    if (fp.counting) hipLaunchKernelGGL((k_extend<false, true>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend<false, false>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+    if (fp.counting) hipLaunchKernelGGL((k_extend<false, true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend<false, false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
   }
 }
 
@@ -488,17 +490,19 @@ void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &
 }
 
 void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,
-                  MirtHitId *out, unsigned long long *counts5, bool any_hit, bool counting) {
+                  MirtHitId *out, unsigned long long *counts5, uint32_t *work, bool any_hit, bool counting) {
   if (n == 0) return;
-  size_t want = (n + 255) / 256;
-  const int blocks = (int)(want < (size_t)cfg.grid_blocks ? want : (size_t)cfg.grid_blocks);
+  // `work` must be zero: the chunk cursor of this launch
+  const size_t want = (n + kChunk - 1) / kChunk / 4 + 1;  // a block's four waves take one chunk each at least
+  const int full = trace_grid_blocks(cfg.num_cus);
+  const dim3 grid((unsigned)(want < (size_t)full ? want : (size_t)full));
   const uint32_t n32 = (uint32_t)n;
   if (any_hit) {
-    if (counting) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
-    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+    if (counting) hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    else hipLaunchKernelGGL((k_trace<true, false>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
   } else {
-    if (counting) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5);
+    if (counting) hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    else hipLaunchKernelGGL((k_trace<false, false>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
   }
 }
 

@@ -119,7 +119,8 @@ class Stats(C.Structure):
                 ("connect_launches", C.c_uint64), ("connect_ms", C.c_double),
                 ("shade_launches", C.c_uint64), ("shade_ms", C.c_double),
                 ("sample_launches", C.c_uint64), ("sample_ms", C.c_double),
-                ("extend_counts", TraversalCounts), ("connect_counts", TraversalCounts)]
+                ("extend_counts", TraversalCounts), ("connect_counts", TraversalCounts),
+                ("engine_phase", C.c_uint64 * 8)]
 
 
 class ConfigInfo(C.Structure):
