@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--paths-per-pixel", type=int, default=8,
+                    help="paths in flight (slots of the wavefront state) per pixel")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -102,7 +104,8 @@ def main():
                                        nee=info.nee)
     pt = pathtracer.Pathtracer(local_rank)
     pt.upload_scene(arrays)
-    pt.create_state(W, H, W * H, src, params)
+    n_paths = W * H * args.paths_per_pixel
+    pt.create_state(W, H, n_paths, src, params)
     pt.set_camera(cam)
 
     spp_step = args.spp_per_step
@@ -200,7 +203,7 @@ def main():
             "config": {"workload": f"config{args.config}: simple_scene (open Cornell box + dragon) {W}x{H}, "
                                    f"{info.max_bounces} bounces, {spp_step} spp per step per GPU, "
                                    f"{'per-material' if info.shade_mode else 'uber'} shading",
-                       "geometry": geometry, "paths_in_flight": W * H, "parallelism": f"spp split x{world}"},
+                       "geometry": geometry, "paths_in_flight": n_paths, "parallelism": f"spp split x{world}"},
             "spp_per_s": samples / (W * H) / elapsed,
             "rays": rays,
             "reduce_ms": reduce_s * 1e3,

@@ -228,16 +228,17 @@ typedef struct MirtStats {
   uint64_t finished_samples;
   uint64_t frames;
   /* per-kernel launch counts and summed HIP-event durations (ms) */
-  uint64_t extend_launches;   double extend_ms;
+  uint64_t extend_launches;   double extend_ms;   /* the closest-hit walk */
+  uint64_t finish_launches;   double finish_ms;   /* its epilogue: hit records and queue routing */
   uint64_t connect_launches;  double connect_ms;
   uint64_t shade_launches;    double shade_ms;
   uint64_t sample_launches;   double sample_ms;
   MirtTraversalCounts extend_counts;  /* filled only when counting is enabled */
   MirtTraversalCounts connect_counts;
-  /* diagnostic builds only (-DMIRT_PHASE_TIMING): shader-clock cycles summed over
-   * waves of the extend kernel: refill, node phase, small-leaf phase, wave-wide
-   * leaf phase, whole kernel; then node-phase iterations, wave-wide leaf
-   * iterations, engine rounds. */
+  /* diagnostic builds only (-DMIRT_PHASE_TIMING), summed over the waves of the
+   * extend kernel: service points, lane node steps, lane triangle steps,
+   * whole-wave leaves, shader-clock cycles, loop iterations, walking lanes summed
+   * over iterations, unused. */
   uint64_t engine_phase[8];
 } MirtStats;
 

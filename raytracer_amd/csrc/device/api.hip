@@ -20,7 +20,7 @@ struct EventPair {
   int kind;
 };
 
-enum KernelKind { K_SAMPLE = 0, K_EXTEND, K_CONNECT, K_SHADE, K_KINDS };
+enum KernelKind { K_SAMPLE = 0, K_EXTEND, K_FINISH, K_CONNECT, K_SHADE, K_KINDS };
 
 }  // namespace
 
@@ -51,8 +51,8 @@ struct mirt_ctx {
   bool counting = false;
   bool event_timing = false;
   std::vector<EventPair> ev_free, ev_pending;
-  double kernel_ms[K_KINDS] = {0, 0, 0, 0};
-  uint64_t kernel_launches[K_KINDS] = {0, 0, 0, 0};
+  double kernel_ms[K_KINDS] = {0, 0, 0, 0, 0};
+  uint64_t kernel_launches[K_KINDS] = {0, 0, 0, 0, 0};
   uint64_t frames_total = 0;
   unsigned long long *h_stats = nullptr;  // pinned, S_COUNT + Q_COUNT words
   unsigned long long *d_trace_counts = nullptr;
@@ -365,6 +365,7 @@ void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_samp
   const DFrameParams fp = frame_params(c, sample_limit, first_sample);
   timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
+  timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
   if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
     if (c->params.nee && fp.have_lights) timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
     timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
@@ -465,32 +466,38 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
   ctx->have_scene = false;
   DScene sc{};
 
-  // TLAS nodes: node i at element i+1 of a 64-B aligned array, so that the
-  // child pair (l, l+1), l odd, shares a 64-B line.
+  // The TLAS-leaf slot list; a leaf of kBigLeaf or more slots keeps its size
+  // out of line, indexed by its first slot.
+  std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
   {
-    std::vector<DNode> nodes(d->n_tlas_nodes + 1);
-    std::vector<uint32_t> big(d->n_tlas_nodes);
-    memset(&nodes[0], 0, sizeof(DNode));
-    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, nodes.data() + 1, big.data());
-    const DNode *p = nullptr;
-    int rc = dev_upload(ctx, ctx->scene_allocs, &p, nodes);
-    if (rc != MIRT_OK) return rc;
-    sc.tlas = p + 1;
-    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_big, big);
-    if (rc != MIRT_OK) return rc;
     std::vector<uint32_t> t2i(d->tlas_to_instances, d->tlas_to_instances + d->n_tlas_to_instances);
-    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_to_inst, t2i);
+    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_to_inst, t2i);
     if (rc != MIRT_OK) return rc;
   }
 
-  // BLAS nodes and triangles, one block per geometry.
+  // Nodes of every tree in one array, 64-B aligned: the TLAS block first, then
+  // one BLAS block per geometry.  Every block starts at an odd element, so the
+  // child pair (l, l+1), l odd, of a node shares a 64-B line.  Triangles per
+  // geometry.
   std::vector<uint32_t> geom_node_base(d->n_geometries), geom_tri_base(d->n_geometries);
   {
     std::vector<DNode> nodes;
     std::vector<DTri> tris(d->n_indices);
     std::vector<DTriN> trins(d->n_indices);
-    nodes.reserve((size_t)d->n_blas_nodes + 2 * d->n_geometries + 1);
+    nodes.reserve((size_t)d->n_tlas_nodes + d->n_blas_nodes + 2 * d->n_geometries + 3);
     nodes.push_back(DNode{});  // element 0 unused: every block starts at an odd element
+    sc.tlas_base = (uint32_t)nodes.size();
+    nodes.resize(nodes.size() + d->n_tlas_nodes);
+    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, nodes.data() + sc.tlas_base, tlas_sizes.data());
+    {
+      std::vector<uint32_t> big(d->n_tlas_to_instances ? d->n_tlas_to_instances : 1u, 0u);
+      for (uint32_t i = 0; i < d->n_tlas_nodes; ++i) {
+        const DNode &dn = nodes[sc.tlas_base + i];
+        if ((dn.b >> 24) == kBigLeaf) big[dn.a] = tlas_sizes[i];
+      }
+      int rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_big, big);
+      if (rc != MIRT_OK) return rc;
+    }
     for (uint32_t g = 0; g < d->n_geometries; ++g) {
       const MirtGeometryOffsets &o = d->geometry_offsets[g];
       const bool last = g + 1 == d->n_geometries;
@@ -529,7 +536,7 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
     const DNode *pn = nullptr;
     int rc = dev_upload(ctx, ctx->scene_allocs, &pn, nodes);
     if (rc != MIRT_OK) return rc;
-    sc.blas = pn;
+    sc.nodes = pn;
     rc = dev_upload(ctx, ctx->scene_allocs, &sc.tri, tris);
     if (rc != MIRT_OK) return rc;
     rc = dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
@@ -894,6 +901,7 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
   }
   out->frames = ctx->frames_total;
   out->extend_launches = ctx->kernel_launches[K_EXTEND];   out->extend_ms = ctx->kernel_ms[K_EXTEND];
+  out->finish_launches = ctx->kernel_launches[K_FINISH];   out->finish_ms = ctx->kernel_ms[K_FINISH];
   out->connect_launches = ctx->kernel_launches[K_CONNECT]; out->connect_ms = ctx->kernel_ms[K_CONNECT];
   out->shade_launches = ctx->kernel_launches[K_SHADE];     out->shade_ms = ctx->kernel_ms[K_SHADE];
   out->sample_launches = ctx->kernel_launches[K_SAMPLE];   out->sample_ms = ctx->kernel_ms[K_SAMPLE];

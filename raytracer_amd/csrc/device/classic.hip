@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
     float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
     const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(scatter)));
     sh4[0] = make_float4(scatter.x, scatter.y, scatter.z, shoot ? prob : 0.0f);
-    sh4[1] = make_float4(__uint_as_float(light_inst), 0.0f, 0.0f, 0.0f);
+    sh4[1] = make_float4(__uint_as_float(light_inst), shoot ? 1.0f : 0.0f, 0.0f, 0.0f);
     r.pos = orig;
     r.dir = scatter;
     r.last_inst = light_inst;
@@ -143,15 +143,15 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
     r.payload = slot;
     if (shoot) traced++;
   };
-  auto finish = [&](bool fin, const RayIn &r, bool occluded, float, const BestHit &) {
-    const uint32_t slot = r.payload;
+  auto finish = [&](bool fin, uint32_t slot, bool occluded, float, const BestHit &) {
     uint32_t kind = 0xFFFFFFFFu;
     if (fin) {
       float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
       float4 s0 = sh4[0];
-      const uint32_t light_inst = __float_as_uint(sh4[1].x);
+      const float4 parked = sh4[1];
+      const uint32_t light_inst = __float_as_uint(parked.x);
       float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (r.tmax >= 0.0f && !occluded) {
+      if (parked.y != 0.0f && !occluded) {
         const DInst *linst = &sc.inst[light_inst];
         if (linst->kind == MIRT_MAT_EMISSIVE) {
           const float *e = sc.emissive + 4 * (size_t)linst->kind_data;

@@ -46,7 +46,11 @@ namespace mirt {
 #endif
 constexpr uint32_t kCoopLeaf = MIRT_COOP_LEAF;
 constexpr int kRefillBelow = MIRT_REFILL_BELOW;  // refill when fewer lanes than this are walking
-constexpr int kNodeBurst = MIRT_NODE_BURST;      // node-step iterations between leaf phases (upper bound)
+#ifndef MIRT_SERVICE_FRAC
+#define MIRT_SERVICE_FRAC 4
+#endif
+constexpr int kServiceFrac = MIRT_SERVICE_FRAC;  // service point when 1/kServiceFrac of the walking lanes are held
+static_assert(MIRT_COOP_LEAF <= 255u, "leaves of kBigLeaf triangles or more must go to the whole-wave phase");
 
 struct LaneCounts {
   uint32_t tlas_nodes = 0, instance_visits = 0, blas_nodes = 0, triangles = 0;
@@ -98,22 +102,24 @@ __device__ __forceinline__ bool ray_box(v3 pos, v3 dinv, const float4 lo, const 
 
 // rayTriIntersect (shaders/ray_extend.slang:53-92) up to the comparison with
 // the current t: returns false when the triangle is missed, else t2, u, v.
+// Written without early exits (the shader's three returns become one
+// predicate) so the three 16-byte loads of a triangle are issued together and
+// lanes do not diverge; a rejected triangle's u, v, t2 may be inf/NaN and are
+// discarded.
 __device__ __forceinline__ bool ray_tri_uvt(v3 pos, v3 dir, v3 p0, v3 e1, v3 e2, float &t2_out, float &u_out,
                                             float &v_out) {
   const v3 q = cross3(dir, e2);
   const float alpha = dot3(e1, q);
-  if (alpha > -(10e-8f) && alpha < 10e-8f) return false;
+  const bool flat = alpha > -(10e-8f) && alpha < 10e-8f;
   const float f = 1.0f / alpha;
   const v3 s = sub3(pos, p0);
   const float u = f * dot3(s, q);
-  if (u < 0.0f) return false;
   const v3 r = cross3(s, e1);
   const float v = f * dot3(dir, r);
-  if (v < 0.0f || u + v > 1.0f) return false;
   t2_out = f * dot3(e2, r);
   u_out = u;
   v_out = v;
-  return true;
+  return !flat && !(u < 0.0f) && !(v < 0.0f || u + v > 1.0f);
 }
 
 // A ray handed to the engine.
@@ -142,6 +148,7 @@ struct WorkSource {
     ph_t0 = ph_now;                                            \
   } while (0)
 #define MIRT_PH_COUNT(k) (ph_acc[k] += 1ull)
+#define MIRT_PH_ADD(k, n) (ph_acc[k] += (unsigned long long)(n))
 #define MIRT_PH_FLUSH(ptr)                                                        \
   do {                                                                            \
     ph_acc[4] = __builtin_amdgcn_s_memtime() - ph_start;                          \
@@ -152,18 +159,46 @@ struct WorkSource {
 #define MIRT_PH_DECL
 #define MIRT_PH_MARK(k)
 #define MIRT_PH_COUNT(k)
+#define MIRT_PH_ADD(k, n)
 #define MIRT_PH_FLUSH(ptr)
 #endif
 
+constexpr uint32_t kEngineBlock = 256u;  // threads per block of every kernel built on the engine
+constexpr uint32_t kNoExclude = 0xFFFFFFFFu;
+
 // The engine.  `fetch(index, ray)` loads entry `index` of the client's queue
-// (called by single lanes); `finish(fin, ray, found, t, best)` is called by ALL
-// lanes at every refill point, with fin = true on the lanes whose ray is done,
-// so it may use wave-aggregated pushes.
+// (called by single lanes); `finish(fin, payload, found, t, best)` is called by
+// ALL lanes at every refill point, with fin = true on the lanes whose ray is
+// done, so it may use wave-aggregated pushes.
+//
+// The kernels built on it are bound by instruction issue, so the loop is
+// arranged to spend as few wave instructions per ray as it can:
+//   - one iteration advances EVERY lane that can move by one unit of work, a
+//     node (one 32-byte fetch, one box test) or a triangle of a small leaf (one
+//     48-byte fetch, one test).  Both kinds use the same address/fetch
+//     instructions and registers; TLAS and BLAS nodes live in one array and
+//     differ only in the lane's base and ray registers;
+//   - everything that happens once per instance or per ray is batched at a
+//     service point, entered when a quarter of the walking lanes are held (or
+//     none can move, or the wave is running low on rays): whole-wave leaves,
+//     housekeeping (leaving a BLAS, turning a TLAS leaf into a slot range,
+//     entering the next instance, ending the walk), handing over finished rays
+//     and fetching new ones.
+//
+// Registers hold only what a step reads (the ray in the current tree's space,
+// t, the cursor, the pending leaf); what is touched once per instance or per
+// ray — the world-space ray, the TLAS cursor and slot range while a BLAS is
+// walked, the exclusion ids, the client's tag and u, v, prim, inst of the best
+// hit so far — lives in LDS, one word column per thread.
 template <bool ANY, bool COUNT, class Fetch, class Finish>
 __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource ws, LaneCounts &lc, Fetch fetch,
                                              Finish finish) {
-  const float4 *tlas4 = reinterpret_cast<const float4 *>(sc.tlas);
-  const float4 *blas4 = reinterpret_cast<const float4 *>(sc.blas);
+  __shared__ float s_ray[9][kEngineBlock];      // world pos, dir, 1/dir
+  __shared__ uint32_t s_tag[3][kEngineBlock];   // last_inst, last_prim, payload
+  __shared__ uint32_t s_best[4][kEngineBlock];  // u bits, v bits, prim, inst
+  __shared__ uint32_t s_tlas[3][kEngineBlock];  // while in a BLAS: TLAS cursor, next slot, end of the slot range
+  const uint32_t tid = threadIdx.x;
+  const float4 *node4 = reinterpret_cast<const float4 *>(sc.nodes);
   const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri);
   const uint32_t lane = trv_lane();
 
@@ -171,248 +206,277 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   uint32_t chunk_next = 0, chunk_end = 0;
   bool exhausted = false;
 
-  // per-lane ray and walk state
-  RayIn ray;
-  ray.pos = V3(0.0f, 0.0f, 0.0f);
-  ray.dir = V3(1.0f, 1.0f, 1.0f);
-  ray.last_inst = ray.last_prim = 0x7FFFFFFFu;
-  ray.tmax = FLT_MAX;
-  ray.payload = 0;
+  // per-lane walk state
   bool has_ray = false, walking = false, found = false;
+  bool in_blas = false;    // the tree being walked is an instance's BLAS
+  bool wrapped = false;    // the cursor is back at the root: this tree is done
+  bool tlas_done = false;  // the TLAS cursor has wrapped (instances of its last leaf may remain)
+  bool hold = false;       // no step until the service point has dealt with the lane
   float t = FLT_MAX;
-  BestHit best;
-  best.t = FLT_MAX;
-  best.u = best.v = 0.0f;
-  best.prim = best.inst = 0;
-  v3 dinv = V3(1.0f, 1.0f, 1.0f);
-  uint32_t tcur = 0, slot_i = 0, slot_end = 0;
-  bool tlas_done = false, in_blas = false, exclude_here = false;
-  uint32_t bcur = 0, id = 0, node_base = 0, tri_base = 0;
-  v3 rpos = ray.pos, rdir = ray.dir, rdinv = dinv;
-  // a leaf waiting for the triangle phase: count == 0 means none
+  uint32_t cur = 0, base = 0, tri_base = 0, id = 0;
+  uint32_t excl_prim = kNoExclude;  // the triangle of this instance the ray must not hit, if any
+  // the ray in the space of the tree being walked (world for the TLAS)
+  v3 cpos = V3(0.0f, 0.0f, 0.0f), cdir = V3(1.0f, 1.0f, 1.0f), cdinv = V3(1.0f, 1.0f, 1.0f);
+  // what is left of the leaf the lane is on: count == 0 means none (BLAS: triangles, TLAS: slots)
   uint32_t leaf_start = 0, leaf_count = 0;
   MIRT_PH_DECL;
 
+  auto accept = [&](float t2, float u, float v, uint32_t p) {
+    t = t2;
+    s_best[0][tid] = __float_as_uint(u);
+    s_best[1][tid] = __float_as_uint(v);
+    s_best[2][tid] = p;
+    s_best[3][tid] = id;
+    found = true;
+    if (ANY) walking = false;  // the first accepted triangle ends an any-hit query
+  };
+
   while (true) {
-    MIRT_PH_COUNT(7);
-    // ------------------------------------------------------- refill point
-    if (__popcll(__ballot(walking)) < kRefillBelow) {
-      const bool fin = has_ray && !walking;
-      if (__ballot(fin) != 0ull) finish(fin, ray, found, t, best);
-      has_ray = has_ray && walking;
-      if (!exhausted) {
-        const unsigned long long need = __ballot(!has_ray);
-        if (chunk_next >= chunk_end) {
-          uint32_t base = 0;
-          if (lane == 0u) base = atomicAdd(ws.counter, kChunk);
-          base = (uint32_t)__shfl((int)base, 0);
-          chunk_next = base < ws.count ? base : ws.count;
-          chunk_end = base + kChunk < ws.count ? base + kChunk : ws.count;
-          if (chunk_next >= chunk_end) exhausted = true;
-        }
-        const uint32_t idx = chunk_next + trv_rank(need);
-        if (!has_ray && idx < chunk_end) {
-          fetch(idx, ray);
-          has_ray = true;
-          walking = !(ray.tmax < 0.0f);  // a negative tmax marks an entry that traces nothing
-          found = false;
-          t = ray.tmax;
-          dinv = V3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
-          tcur = 0u;
-          tlas_done = false;
-          slot_i = slot_end = 0u;
-          in_blas = false;
-          leaf_count = 0u;
-        }
-        const uint32_t taken = (uint32_t)__popcll(need);
-        chunk_next = chunk_next + taken < chunk_end ? chunk_next + taken : chunk_end;
-      }
-      if (__ballot(walking) == 0ull) {
-        if (exhausted) break;
-        continue;  // the chunk ran dry: grab the next one
-      }
-    }
-    MIRT_PH_MARK(0);
-
-    // --------------------------------------------------------- node phase
-    // Lanes without a parked leaf advance their walk; the phase ends when no
-    // lane can step, after kNodeBurst steps, or when more lanes wait on a
-    // parked leaf than are stepping.
-    for (int burst = 0; burst < kNodeBurst; ++burst) {
-      const bool can_step = walking && leaf_count == 0u;
-      const unsigned long long stepping = __ballot(can_step);
-      if (stepping == 0ull) break;
-      if (burst > 0 && __popcll(stepping) < __popcll(__ballot(walking && leaf_count != 0u))) break;
-      MIRT_PH_COUNT(5);
-      if (can_step) {
-        if (in_blas) {
-          // one BLAS node (blasFirstHit, shaders/ray_extend.slang:127-142)
-          const size_t ni = (size_t)(node_base + bcur);
-          const float4 blo = blas4[2 * ni], bhi = blas4[2 * ni + 1];
-          if (COUNT) lc.blas_nodes++;
-          float bt0, bt1;
-          const bool bhit = ray_box(rpos, rdinv, blo, bhi, t, bt0, bt1);
-          const uint32_t ba = __float_as_uint(blo.w), bb = __float_as_uint(bhi.w);
-          const uint32_t bleaf = bb >> 24;
-          bcur = (bhit && bleaf == 0u) ? ba : (bb & kSkipMask);
-          if (bhit && bleaf != 0u) {
-            leaf_start = ba;
-            leaf_count = bleaf == kBigLeaf ? sc.tri[tri_base + ba].p0w : bleaf;
-          }
-          if (bcur == 0u) in_blas = false;
-        } else if (slot_i < slot_end) {
-          // enter the next instance of the current TLAS leaf
-          // (shaders/ray_extend.slang:190-203); matrices were built on the host
-          id = sc.tlas_to_inst[slot_i++];
-          const DInst *inst = &sc.inst[id];
-          if (COUNT) lc.instance_visits++;
-          const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
-          const float4 m1 = reinterpret_cast<const float4 *>(inst->mi)[1];
-          const float4 m2 = reinterpret_cast<const float4 *>(inst->mi)[2];
-          node_base = inst->node_base;
-          tri_base = inst->tri_base;
-          const v3 pos = ray.pos, dir = ray.dir;
-          rpos = V3(__builtin_fmaf(m0.z, pos.z, __builtin_fmaf(m0.y, pos.y, m0.x * pos.x)) + m0.w,
-                    __builtin_fmaf(m1.z, pos.z, __builtin_fmaf(m1.y, pos.y, m1.x * pos.x)) + m1.w,
-                    __builtin_fmaf(m2.z, pos.z, __builtin_fmaf(m2.y, pos.y, m2.x * pos.x)) + m2.w);
-          rdir = V3(__builtin_fmaf(m0.z, dir.z, __builtin_fmaf(m0.y, dir.y, m0.x * dir.x)),
-                    __builtin_fmaf(m1.z, dir.z, __builtin_fmaf(m1.y, dir.y, m1.x * dir.x)),
-                    __builtin_fmaf(m2.z, dir.z, __builtin_fmaf(m2.y, dir.y, m2.x * dir.x)));
-          rdinv = V3(1.0f / rdir.x, 1.0f / rdir.y, 1.0f / rdir.z);
-          exclude_here = id == ray.last_inst;
-          bcur = 0u;
-          in_blas = true;
-        } else if (!tlas_done) {
-          // one TLAS node (tlasFirstHit, shaders/ray_extend.slang:173-188)
-          const float4 lo = tlas4[2 * tcur], hi = tlas4[2 * tcur + 1];
-          if (COUNT) lc.tlas_nodes++;
-          float tmin_aabb, tmax_aabb;
-          const bool hit_aabb =
-              ray_box(ray.pos, dinv, lo, hi, t, tmin_aabb, tmax_aabb) && (tmax_aabb >= 0.0f || tmin_aabb >= 0.0f);
-          const uint32_t wa = __float_as_uint(lo.w), wb = __float_as_uint(hi.w);
-          const uint32_t leaf = wb >> 24;
-          if (hit_aabb && leaf != 0u) {
-            slot_i = wa;
-            slot_end = wa + (leaf == kBigLeaf ? sc.tlas_big[tcur] : leaf);
-          }
-          tcur = (hit_aabb && leaf == 0u) ? wa : (wb & kSkipMask);
-          if (tcur == 0u) tlas_done = true;
-        } else {
-          walking = false;
-        }
-      }
-    }
-
-    MIRT_PH_MARK(1);
-    // ------------------------------------------------- small-leaf phase
-    // every lane with a parked leaf of fewer than kCoopLeaf triangles scans it
-    {
-      const bool small = walking && leaf_count != 0u && leaf_count < kCoopLeaf;
-      uint32_t j = 0;
-      while (__ballot(small && j < leaf_count) != 0ull) {
-        if (small && j < leaf_count) {
-          const uint32_t p = leaf_start + j;
-          if (!(exclude_here && p == ray.last_prim)) {
-            const size_t ti = 3 * (size_t)(tri_base + p);
+    const int n_walking = __popcll(__ballot(walking));
+    const int n_held = __popcll(__ballot(walking && hold));
+    if ((n_held != 0 && kServiceFrac * n_held >= n_walking) || n_held == n_walking || (!exhausted && n_walking < kRefillBelow)) {
+      MIRT_PH_COUNT(0);
+      // ================================================== service point
+      // ------------------------------------- leaves for the whole wave
+      {
+        unsigned long long bigmask = __ballot(walking && hold && in_blas && leaf_count != 0u);
+        const bool any_big = bigmask != 0ull;
+        while (bigmask != 0ull) {
+          const int owner = __ffsll((long long)bigmask) - 1;
+          bigmask &= bigmask - 1ull;
+          MIRT_PH_COUNT(3);
+          // the owner's ray and leaf, wave-uniform (scalar registers)
+          auto bcast_f = [&](float x) {
+            return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), owner));
+          };
+          auto bcast_u = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, owner); };
+          const v3 op = V3(bcast_f(cpos.x), bcast_f(cpos.y), bcast_f(cpos.z));
+          const v3 od = V3(bcast_f(cdir.x), bcast_f(cdir.y), bcast_f(cdir.z));
+          const float ot = bcast_f(t);
+          const uint32_t ostart = bcast_u(leaf_start);
+          const uint32_t otri_base = bcast_u(tri_base);
+          uint32_t ocount = bcast_u(leaf_count);
+          if (ocount == kBigLeaf) ocount = sc.tri[otri_base + ostart].p0w;  // size stored out of line
+          const uint32_t oskip = bcast_u(excl_prim);
+          // per-lane best over triangles ostart + lane, + 64, ...
+          // key: ANY -> index (first accepted in index order);
+          //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
+          unsigned long long key = ~0ull;
+          float ku = 0.0f, kv = 0.0f, kt = 0.0f;
+          for (uint32_t k = lane; k < ocount; k += 64u) {
+            const uint32_t p = ostart + k;
+            if (p == oskip) continue;
+            const size_t ti = 3 * (size_t)(otri_base + p);
             const float4 a0 = tri4[ti], a1 = tri4[ti + 1], a2 = tri4[ti + 2];
-            if (COUNT) lc.triangles++;
             float t2, u, v;
-            if (ray_tri_uvt(rpos, rdir, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
-                !(t2 > t || t2 < 0.0f)) {
-              t = t2;
-              best.t = t2;
-              best.u = u;
-              best.v = v;
-              best.prim = p;
-              best.inst = id;
-              found = true;
-              if (ANY) {
-                walking = false;
-                j = leaf_count;  // the first accepted triangle ends an any-hit query
+            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+                !(t2 > ot || t2 < 0.0f)) {
+              const unsigned long long kk =
+                  ANY ? (unsigned long long)p
+                      : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
+              if (kk < key) {
+                key = kk;
+                ku = u;
+                kv = v;
+                kt = t2;
+              }
+              if (ANY) break;  // later triangles of this lane have higher indices
+            }
+          }
+          unsigned long long wkey = key;
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_xor(wkey, off);
+            wkey = other < wkey ? other : wkey;
+          }
+          const bool mine = (int)lane == owner;
+          if (wkey != ~0ull) {
+            const int winner = __ffsll((long long)__ballot(key == wkey)) - 1;
+            const float wu = __shfl(ku, winner), wv = __shfl(kv, winner), wt = __shfl(kt, winner);
+            const uint32_t wp = ANY ? (uint32_t)wkey : ~(uint32_t)wkey;
+            if (mine) accept(wt, wu, wv, wp);
+            if (COUNT && mine) {
+              // a scan tests every triangle (ANY: up to the first accepted one) except the excluded one
+              const uint32_t tested = ANY ? (wp - ostart + 1u) : ocount;
+              const bool skipped = oskip >= ostart && oskip < ostart + tested;
+              lc.triangles += tested - (skipped ? 1u : 0u);
+            }
+          } else if (COUNT && mine) {
+            const bool skipped = oskip >= ostart && oskip < ostart + ocount;
+            lc.triangles += ocount - (skipped ? 1u : 0u);
+          }
+          if (mine) {
+            leaf_count = 0u;
+            hold = wrapped;
+          }
+        }
+        // 1/dir is not needed by the scan: rebuilding it here (same operation, same
+        // bits) instead of keeping it frees its registers for the scan
+        if (any_big) cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+      }
+
+      // ---------------------------------------------------- housekeeping
+      // Held lanes with no triangle leaf left: a BLAS walk that is done goes back
+      // to the TLAS; a TLAS leaf becomes a slot range; the next instance of the
+      // range is entered (shaders/ray_extend.slang:190-203; matrices were built
+      // on the host); with nothing left the walk ends.
+      {
+        const bool hk = walking && hold;
+        if (__ballot(hk) != 0ull) {
+          if (hk) {
+            uint32_t slot_i = 0u, slot_end = 0u;
+            if (in_blas) {
+              in_blas = false;
+              cpos = V3(s_ray[0][tid], s_ray[1][tid], s_ray[2][tid]);
+              cdir = V3(s_ray[3][tid], s_ray[4][tid], s_ray[5][tid]);
+              cdinv = V3(s_ray[6][tid], s_ray[7][tid], s_ray[8][tid]);
+              cur = s_tlas[0][tid];
+              slot_i = s_tlas[1][tid];
+              slot_end = s_tlas[2][tid];
+              base = sc.tlas_base;
+            } else {
+              if (wrapped) tlas_done = true;
+              if (leaf_count != 0u) {
+                slot_i = leaf_start;
+                slot_end = leaf_start + (leaf_count == kBigLeaf ? sc.tlas_big[leaf_start] : leaf_count);
+                leaf_count = 0u;
               }
             }
+            if (slot_i < slot_end) {
+              id = sc.tlas_to_inst[slot_i];
+              const DInst *inst = &sc.inst[id];
+              if (COUNT) lc.instance_visits++;
+              const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
+              const float4 m1 = reinterpret_cast<const float4 *>(inst->mi)[1];
+              const float4 m2 = reinterpret_cast<const float4 *>(inst->mi)[2];
+              s_tlas[0][tid] = cur;
+              s_tlas[1][tid] = slot_i + 1u;
+              s_tlas[2][tid] = slot_end;
+              base = inst->node_base;
+              tri_base = inst->tri_base;
+              const v3 pos = cpos, dir = cdir;  // the world-space ray
+              cpos = V3(__builtin_fmaf(m0.z, pos.z, __builtin_fmaf(m0.y, pos.y, m0.x * pos.x)) + m0.w,
+                        __builtin_fmaf(m1.z, pos.z, __builtin_fmaf(m1.y, pos.y, m1.x * pos.x)) + m1.w,
+                        __builtin_fmaf(m2.z, pos.z, __builtin_fmaf(m2.y, pos.y, m2.x * pos.x)) + m2.w);
+              cdir = V3(__builtin_fmaf(m0.z, dir.z, __builtin_fmaf(m0.y, dir.y, m0.x * dir.x)),
+                        __builtin_fmaf(m1.z, dir.z, __builtin_fmaf(m1.y, dir.y, m1.x * dir.x)),
+                        __builtin_fmaf(m2.z, dir.z, __builtin_fmaf(m2.y, dir.y, m2.x * dir.x)));
+              cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+              excl_prim = id == s_tag[0][tid] ? s_tag[1][tid] : kNoExclude;
+              cur = 0u;
+              in_blas = true;
+              wrapped = hold = false;
+            } else if (tlas_done) {
+              walking = false;
+            } else {
+              wrapped = hold = false;
+            }
           }
         }
-        ++j;
       }
-      if (small) leaf_count = 0u;
+
+      // ---------------------------------------------------------- refill
+      {
+        const bool fin = has_ray && !walking;
+        if (__ballot(fin) != 0ull) {
+          BestHit best;
+          best.t = t;
+          best.u = __uint_as_float(s_best[0][tid]);
+          best.v = __uint_as_float(s_best[1][tid]);
+          best.prim = s_best[2][tid];
+          best.inst = s_best[3][tid];
+          finish(fin, s_tag[2][tid], found, t, best);
+        }
+        has_ray = has_ray && walking;
+        if (!exhausted && __popcll(__ballot(walking)) < kRefillBelow) {
+          const unsigned long long need = __ballot(!has_ray);
+          if (chunk_next >= chunk_end) {
+            uint32_t cbase = 0;
+            if (lane == 0u) cbase = atomicAdd(ws.counter, kChunk);
+            cbase = (uint32_t)__shfl((int)cbase, 0);
+            chunk_next = cbase < ws.count ? cbase : ws.count;
+            chunk_end = cbase + kChunk < ws.count ? cbase + kChunk : ws.count;
+            if (chunk_next >= chunk_end) exhausted = true;
+          }
+          const uint32_t idx = chunk_next + trv_rank(need);
+          if (!has_ray && idx < chunk_end) {
+            RayIn ray;
+            fetch(idx, ray);
+            has_ray = true;
+            walking = !(ray.tmax < 0.0f);  // a negative tmax marks an entry that traces nothing
+            found = false;
+            t = ray.tmax;
+            cpos = ray.pos;
+            cdir = ray.dir;
+            cdinv = V3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+            s_ray[0][tid] = cpos.x;
+            s_ray[1][tid] = cpos.y;
+            s_ray[2][tid] = cpos.z;
+            s_ray[3][tid] = cdir.x;
+            s_ray[4][tid] = cdir.y;
+            s_ray[5][tid] = cdir.z;
+            s_ray[6][tid] = cdinv.x;
+            s_ray[7][tid] = cdinv.y;
+            s_ray[8][tid] = cdinv.z;
+            s_tag[0][tid] = ray.last_inst;
+            s_tag[1][tid] = ray.last_prim;
+            s_tag[2][tid] = ray.payload;
+            cur = 0u;
+            base = sc.tlas_base;
+            in_blas = wrapped = tlas_done = hold = false;
+            leaf_count = 0u;
+          }
+          const uint32_t taken = (uint32_t)__popcll(need);
+          chunk_next = chunk_next + taken < chunk_end ? chunk_next + taken : chunk_end;
+        }
+        if (__ballot(has_ray) == 0ull && exhausted) break;
+      }
     }
 
-    MIRT_PH_MARK(2);
-    // ------------------------------------- leaves for the whole wave
-    {
-      unsigned long long bigmask = __ballot(walking && leaf_count >= kCoopLeaf);
-      while (bigmask != 0ull) {
-        const int owner = __ffsll((long long)bigmask) - 1;
-        bigmask &= bigmask - 1ull;
-        const v3 op = V3(__shfl(rpos.x, owner), __shfl(rpos.y, owner), __shfl(rpos.z, owner));
-        const v3 od = V3(__shfl(rdir.x, owner), __shfl(rdir.y, owner), __shfl(rdir.z, owner));
-        const float ot = __shfl(t, owner);
-        const uint32_t ostart = (uint32_t)__shfl((int)leaf_start, owner);
-        const uint32_t ocount = (uint32_t)__shfl((int)leaf_count, owner);
-        const uint32_t otri_base = (uint32_t)__shfl((int)tri_base, owner);
-        const uint32_t oskip =
-            __shfl((int)exclude_here, owner) ? (uint32_t)__shfl((int)ray.last_prim, owner) : 0xFFFFFFFFu;
-        // per-lane best over triangles ostart + lane, + 64, ...
-        // key: ANY -> index (first accepted in index order);
-        //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
-        unsigned long long key = ~0ull;
-        float ku = 0.0f, kv = 0.0f, kt = 0.0f;
-        for (uint32_t k = lane; k < ocount; k += 64u) {
-          MIRT_PH_COUNT(6);
-          const uint32_t p = ostart + k;
-          if (p == oskip) continue;
-          const size_t ti = 3 * (size_t)(otri_base + p);
-          const float4 a0 = tri4[ti], a1 = tri4[ti + 1], a2 = tri4[ti + 2];
-          float t2, u, v;
-          if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
-              !(t2 > ot || t2 < 0.0f)) {
-            const unsigned long long kk =
-                ANY ? (unsigned long long)p
-                    : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
-            if (kk < key) {
-              key = kk;
-              ku = u;
-              kv = v;
-              kt = t2;
-            }
-            if (ANY) break;  // later triangles of this lane have higher indices
-          }
+    // ================================================================ step
+    // One unit of work for every lane that can move: the next triangle of its
+    // leaf, else the node under its cursor (blasFirstHit / tlasFirstHit,
+    // shaders/ray_extend.slang:127-142, 173-188).
+    MIRT_PH_COUNT(5);
+    MIRT_PH_ADD(6, __popcll(__ballot(walking)));
+    MIRT_PH_ADD(1, __popcll(__ballot(walking && !hold && leaf_count == 0u)));
+    MIRT_PH_ADD(2, __popcll(__ballot(walking && !hold && leaf_count != 0u)));
+    if (walking && !hold) {
+      const bool is_tri = leaf_count != 0u;
+      const float4 *p4 =
+          is_tri ? tri4 + 3 * (size_t)(tri_base + leaf_start) : node4 + 2 * (size_t)(base + cur);
+      const float4 a0 = p4[0], a1 = p4[1];
+      float4 a2 = a1;
+      if (is_tri) a2 = p4[2];  // issued with the other two, before either test
+      if (!is_tri) {
+        if (COUNT) {
+          if (in_blas) lc.blas_nodes++;
+          else lc.tlas_nodes++;
         }
-        unsigned long long wkey = key;
-        for (int off = 32; off > 0; off >>= 1) {
-          const unsigned long long other = __shfl_xor(wkey, off);
-          wkey = other < wkey ? other : wkey;
+        float t0, t1;
+        bool hit = ray_box(cpos, cdinv, a0, a1, t, t0, t1);
+        hit = hit && (in_blas || t1 >= 0.0f || t0 >= 0.0f);  // the TLAS also rejects boxes behind the ray
+        const uint32_t wa = __float_as_uint(a0.w), wb = __float_as_uint(a1.w);
+        const uint32_t leaf = wb >> 24;
+        const bool leaf_hit = hit && leaf != 0u;
+        cur = (hit && leaf == 0u) ? wa : (wb & kSkipMask);
+        leaf_start = wa;
+        leaf_count = leaf_hit ? leaf : 0u;  // kBigLeaf is resolved by whoever takes the leaf
+        wrapped = cur == 0u;
+        // small BLAS leaves are scanned by the lane itself; everything else waits for the service point
+        hold = leaf_hit ? (!in_blas || leaf >= kCoopLeaf) : wrapped;
+      } else {
+        const uint32_t p = leaf_start;
+        float t2, u, v;
+        const bool ok = ray_tri_uvt(cpos, cdir, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v);
+        leaf_start = p + 1u;
+        leaf_count -= 1u;
+        if (leaf_count == 0u) hold = wrapped;
+        if (p != excl_prim) {
+          if (COUNT) lc.triangles++;
+          if (ok && !(t2 > t || t2 < 0.0f)) accept(t2, u, v, p);
         }
-        const bool mine = (int)lane == owner;
-        if (wkey != ~0ull) {
-          const int winner = __ffsll((long long)__ballot(key == wkey)) - 1;
-          const float wu = __shfl(ku, winner), wv = __shfl(kv, winner), wt = __shfl(kt, winner);
-          const uint32_t wp = ANY ? (uint32_t)wkey : ~(uint32_t)wkey;
-          if (mine) {
-            t = wt;
-            best.t = wt;
-            best.u = wu;
-            best.v = wv;
-            best.prim = wp;
-            best.inst = id;
-            found = true;
-            if (ANY) walking = false;
-          }
-          if (COUNT && mine) {
-            // a scan tests every triangle (ANY: up to the first accepted one) except the excluded one
-            const uint32_t tested = ANY ? (wp - ostart + 1u) : ocount;
-            const bool skipped = oskip >= ostart && oskip < ostart + tested;
-            lc.triangles += tested - (skipped ? 1u : 0u);
-          }
-        } else if (COUNT && mine) {
-          const bool skipped = oskip >= ostart && oskip < ostart + ocount;
-          lc.triangles += ocount - (skipped ? 1u : 0u);
-        }
-        if (mine) leaf_count = 0u;
       }
     }
-    MIRT_PH_MARK(3);
   }
   MIRT_PH_FLUSH(ws.phase);
 }

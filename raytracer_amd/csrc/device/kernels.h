@@ -68,6 +68,7 @@ int trace_grid_blocks(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);

@@ -150,13 +150,22 @@ __global__ __launch_bounds__(256) void k_init_slots(DState st) {
 
 // ---------------------------------------------------------------- extend
 
-template <bool CLASSIC, bool COUNT>
-__global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFrameParams fp) {
+// The closest-hit walk of extensionMain (shaders/ray_extend.slang:12-33) for
+// every entry of this frame's extension queue.  It leaves the raw result in the
+// slot's hit record — u, v, t and the instance (kMissInst when nothing was hit)
+// in the first 16 bytes, the triangle id in the last word — for
+// k_extend_finish; keeping the epilogue out of this kernel keeps its register
+// count at eight waves per SIMD.
+constexpr uint32_t kMissInst = 0xFFFFFFFFu;
+#ifndef MIRT_EXTEND_WAVES
+#define MIRT_EXTEND_WAVES 5  // waves per SIMD the register allocation must allow
+#endif
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, MIRT_EXTEND_WAVES) void k_extend(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
-  uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
   LaneCounts lc;
 
   auto fetch = [&](uint32_t idx, RayIn &r) {
@@ -165,15 +174,47 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
     r.tmax = FLT_MAX;
     r.payload = slot;
   };
-  // extensionMain's epilogue (shaders/ray_extend.slang:34-50) for the lanes
-  // whose ray is done; called by the whole wave so the pushes can aggregate
-  auto finish = [&](bool fin, const RayIn &r, bool found, float, const BestHit &best) {
-    const uint32_t slot = r.payload;
-    bool hit = fin && found;
+  auto finish = [&](bool fin, uint32_t slot, bool found, float t, const BestHit &best) {
+    if (fin) {
+      float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+      h4[0] = make_float4(best.u, best.v, t, __uint_as_float(found ? best.inst : kMissInst));
+      reinterpret_cast<uint32_t *>(h4)[7] = best.prim;
+    }
+  };
+  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
+  if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
+}
+
+// extensionMain's epilogue (shaders/ray_extend.slang:34-50), one thread per
+// entry of the extension queue: a miss adds the sky and ends the path, a hit
+// gets its world-space record and goes to the shading queue(s).
+template <bool CLASSIC>
+__global__ __launch_bounds__(256) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_EXT0 + par];
+  uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
+  uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
+  const uint32_t stride = gridDim.x * 256u;
+  for (uint32_t base = blockIdx.x * 256u; base < count; base += stride) {  // uniform per block
+    const uint32_t i = base + threadIdx.x;
+    const bool fin = i < count;
+    uint32_t slot = 0;
+    bool hit = false;
     uint32_t route = 0;  // classic: queue of the hit material
     if (fin) {
+      slot = ext[i];
       DPath *pp = st.path + slot;
-      if (!found) {
+      float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+      const float4 raw = h4[0];
+      BestHit best;
+      best.u = raw.x;
+      best.v = raw.y;
+      best.t = raw.z;
+      best.inst = __float_as_uint(raw.w);
+      if (best.inst == kMissInst) {
         // rad += throughput * sky
         float4 *p4 = reinterpret_cast<float4 *>(pp);
         float4 a = p4[0];
@@ -184,10 +225,13 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
         a.z = a.z + b.z * sky;
         p4[0] = a;
       } else {
+        hit = true;
+        best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
+        const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
+        const float4 ra = r4[0], rb = r4[1];
         v3 hp, hn;
         uint32_t ff;
-        finish_hit(sc, r.dir, best, hp, hn, ff);
-        float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+        finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
         h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
         h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
         if (CLASSIC) {
@@ -207,20 +251,17 @@ __global__ __launch_bounds__(256) void k_extend(DScene sc, DState st, DFramePara
         }
       }
     }
-    wave_push(term_cnt, term, fin && !hit, slot);
     if (!CLASSIC) {
-      wave_push(&st.qcount[Q_SHADE], st.qdata[Q_SHADE], hit, slot);
+      block_push2(sh, term_cnt, term, fin && !hit, &st.qcount[Q_SHADE], st.qdata[Q_SHADE], hit, slot);
     } else {
+      wave_push(term_cnt, term, fin && !hit, slot);
       wave_push(&st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], hit && route == Q_CONNECT, slot);
       wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], hit && route == Q_LAMBERTIAN, slot);
       wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], hit && route == Q_METALLIC, slot);
       wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
       wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
     }
-  };
-  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
-  if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
+  }
 }
 
 // ------------------------------------------------------------ shade (uber)
@@ -413,7 +454,7 @@ __global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, cons
     r.tmax = ANY ? tmax[idx] : FLT_MAX;
     r.payload = idx;
   };
-  auto finish = [&](bool fin, const RayIn &r, bool found, float t, const BestHit &best) {
+  auto finish = [&](bool fin, uint32_t idx, bool found, float t, const BestHit &best) {
     if (!fin) return;
     MirtHitId o{0xFFFFFFFFu, 0xFFFFFFFFu, FLT_MAX, 0u};
     if (found) {
@@ -421,13 +462,14 @@ __global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, cons
       o.triangle_id = best.prim;
       o.t = t;
       if (!ANY) {
-        v3 hp, hn;
-        uint32_t ff;
-        finish_hit(sc, r.dir, best, hp, hn, ff);
+        v3 pos, dir, hp, hn;
+        uint32_t li, lp, ff;
+        load_ray(rays, idx, pos, dir, li, lp);
+        finish_hit(sc, dir, best, hp, hn, ff);
         o.front_face = ff;
       }
     }
-    reinterpret_cast<float4 *>(out)[r.payload] =
+    reinterpret_cast<float4 *>(out)[idx] =
         make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
   };
   trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr}, lc, fetch, finish);
@@ -463,22 +505,24 @@ int trace_grid_blocks(int num_cus) {
   static int per_cu = 0;
   if (per_cu == 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false, false>, 256, 0) != hipSuccess || n < 1) n = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, 256, 0) != hipSuccess || n < 1) n = 4;
     per_cu = n > 8 ? 8 : n;
   }
   return per_cu * num_cus;
 }
 
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  const bool classic = fp.p.shade_mode == MIRT_SHADE_CLASSIC;
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
-  if (classic) {
-    if (fp.counting) hipLaunchKernelGGL((k_extend<true, true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend<true, false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-  } else {
-    if (fp.counting) hipLaunchKernelGGL((k_extend<false, true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend<false, false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-  }
+  if (fp.counting) hipLaunchKernelGGL((k_extend<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_extend<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+}
+
+void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  const dim3 grid(cfg.grid_blocks);
+  if (fp.p.shade_mode == MIRT_SHADE_CLASSIC)
+    hipLaunchKernelGGL((k_extend_finish<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  else
+    hipLaunchKernelGGL((k_extend_finish<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

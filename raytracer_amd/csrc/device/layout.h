@@ -32,7 +32,7 @@ namespace mirt {
 // word b: bits 0..23 skip link (next node when this subtree is done),
 //         bits 24..31 leaf size: 0 = inner, 1..254 = leaf with that many
 //         primitives, 255 = leaf whose size is stored out of line
-//         (BLAS: bits of DTri[start].p0w; TLAS: tlas_big[node]).
+//         (BLAS: bits of DTri[start].p0w; TLAS: tlas_big[start]).
 // word a: inner -> left child; leaf -> first primitive (BLAS-local triangle id
 //         or TLAS slot).
 struct DNode {
@@ -115,11 +115,11 @@ static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
 // Everything a traversal needs, passed by value to the kernels.
 struct DScene {
-  const DNode *tlas;          // node i at tlas[i]
-  const uint32_t *tlas_big;   // out-of-line leaf sizes, one per TLAS node
+  const DNode *nodes;         // every tree: node i of a tree at nodes[base + i]
+  uint32_t tlas_base;         // base of the TLAS
+  const uint32_t *tlas_big;   // out-of-line TLAS leaf sizes, indexed by the leaf's first slot
   const uint32_t *tlas_to_inst;
   const DInst *inst;
-  const DNode *blas;          // all BLAS node blocks
   const DTri *tri;
   const DTriN *trin;
   const DMaterial *mat;

@@ -116,6 +116,7 @@ class Stats(C.Structure):
                 ("shade_events", C.c_uint64), ("spawned_samples", C.c_uint64),
                 ("finished_samples", C.c_uint64), ("frames", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
+                ("finish_launches", C.c_uint64), ("finish_ms", C.c_double),
                 ("connect_launches", C.c_uint64), ("connect_ms", C.c_double),
                 ("shade_launches", C.c_uint64), ("shade_ms", C.c_double),
                 ("sample_launches", C.c_uint64), ("sample_ms", C.c_double),

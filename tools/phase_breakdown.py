@@ -8,15 +8,15 @@ arrays, info = host.build_config_scene(3)
 W, H = 1920, 1080
 src = host.make_sample_sources(W, H, info.seed); cam = host.default_camera(W, H)
 pt = pathtracer.Pathtracer(0); pt.upload_scene(arrays)
-pt.create_state(W, H, W * H, src, pathtracer.default_params(max_bounces=8, seed=info.seed)); pt.set_camera(cam)
+PPP = int(os.environ.get('PPP', '8'))
+pt.create_state(W, H, W * H * PPP, src, pathtracer.default_params(max_bounces=8, seed=info.seed)); pt.set_camera(cam)
 pt.render_spp(2); pt.stats_reset(); pt.set_event_timing(True)
-t = time.time(); pt.render_spp(4); dt = time.time() - t; st = pt.stats()
+t = time.time(); pt.render_spp(4 * PPP); dt = time.time() - t; st = pt.stats()
 ph = list(st.engine_phase)
 print(f"{st.extend_rays/dt/1e6:.1f} Mrays/s, extend {st.extend_ms/st.extend_launches:.3f} ms/launch x {st.extend_launches}")
-if ph[4]:
-    names = ["refill", "node", "small-leaf", "coop-leaf"]
-    tot = ph[4]
-    for n, v in zip(names, ph[:4]):
-        print(f"  {n:<11} {100*v/tot:5.1f} % of wave cycles")
-    print(f"  node-phase iterations {ph[5]:.3e} ({ph[1]/max(ph[5],1):.0f} cyc each); coop iterations {ph[6]/64:.3e} wave-its ({ph[3]/max(ph[6]/64,1):.0f} cyc each); rounds {ph[7]:.3e}")
-    print(f"  rays {st.extend_rays}: node its per ray-wave {ph[5]*64/st.extend_rays:.1f}")
+if ph[5]:
+    its = ph[5]
+    rw = st.extend_rays / 64.0
+    print(f"  iterations {its:.3e} ({its/rw:.1f} per 64 rays), service points {ph[0]:.3e} ({ph[0]/rw:.1f} per 64 rays), whole-wave leaves {ph[3]:.3e}")
+    print(f"  lanes per iteration: walking {ph[6]/its:.1f}, node steps {ph[1]/its:.1f}, triangle steps {ph[2]/its:.1f}")
+    print(f"  per ray: node steps {ph[1]/st.extend_rays:.1f}, lane triangle steps {ph[2]/st.extend_rays:.1f}")
