@@ -214,6 +214,7 @@ bool validate_scene(const MirtSceneDesc *d, std::string &why) {
       return bad("geometry offsets are not ascending or exceed the buffers");
     const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index, nv = vtx_end - o.vertex;
     if (nn > kMaxNodesPerTree) return bad("a BLAS has more than 2^24 nodes");
+    if (ni > kMaxNodesPerTree) return bad("a geometry has more than 2^24 triangles");
     for (uint32_t i = 0; i < nn; ++i) {
       const MirtBVHNode &n = d->blas_nodes[o.blas_node + i];
       if (n.right >= nn) return bad("BLAS skip link out of range");
@@ -533,12 +534,24 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
       }
     }
     if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
-    const DNode *pn = nullptr;
-    int rc = dev_upload(ctx, ctx->scene_allocs, &pn, nodes);
+    // Nodes and triangles share one allocation so that the traversal kernels
+    // address both through one buffer descriptor and 32-bit byte offsets.
+    const size_t node_bytes = nodes.size() * sizeof(DNode);
+    const size_t tri_off = (node_bytes + 255u) & ~(size_t)255u;
+    const size_t geo_bytes = tri_off + tris.size() * sizeof(DTri) + 64u;  // tail pad: 16-byte reads past the last record stay inside
+    if (geo_bytes >= ((size_t)1 << 32))
+      return fail(ctx, MIRT_ERR_BAD_SCENE, "nodes and triangles exceed the 4 GiB the traversal kernels address");
+    std::vector<unsigned char> geo(geo_bytes, 0);
+    memcpy(geo.data(), nodes.data(), node_bytes);
+    if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
+    const unsigned char *pg = nullptr;
+    int rc = dev_upload(ctx, ctx->scene_allocs, &pg, geo);
     if (rc != MIRT_OK) return rc;
-    sc.nodes = pn;
-    rc = dev_upload(ctx, ctx->scene_allocs, &sc.tri, tris);
-    if (rc != MIRT_OK) return rc;
+    sc.geo = pg;
+    sc.geo_bytes = (uint32_t)geo_bytes;
+    sc.tri_off = (uint32_t)tri_off;
+    sc.nodes = reinterpret_cast<const DNode *>(pg);
+    sc.tri = reinterpret_cast<const DTri *>(pg + tri_off);
     rc = dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
     if (rc != MIRT_OK) return rc;
   }

@@ -115,12 +115,14 @@ static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
 // Everything a traversal needs, passed by value to the kernels.
 struct DScene {
-  const DNode *nodes;         // every tree: node i of a tree at nodes[base + i]
+  const unsigned char *geo;   // one allocation: the node array, then (at tri_off) the DTri array
+  uint32_t geo_bytes, tri_off;
+  const DNode *nodes;         // = geo; every tree: node i of a tree at nodes[base + i]
   uint32_t tlas_base;         // base of the TLAS
   const uint32_t *tlas_big;   // out-of-line TLAS leaf sizes, indexed by the leaf's first slot
   const uint32_t *tlas_to_inst;
   const DInst *inst;
-  const DTri *tri;
+  const DTri *tri;            // = geo + tri_off
   const DTriN *trin;
   const DMaterial *mat;
   const uint32_t *lights;     // instance ids
