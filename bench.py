@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=32)
     ap.add_argument("--paths-per-pixel", type=int, default=8,
                     help="paths in flight (slots of the wavefront state) per pixel")
@@ -58,24 +58,28 @@ def parse():
 
 def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
     """The CPU oracle (a port of the reference's kernels, OpenMP over samples) on
-    this host's cores, on the first sources of the same workload at 1 spp."""
+    this host's cores, on a bounded sample of the same workload: a pilot run sizes
+    the timed run (sources x spp) to about `target_seconds` of CPU work."""
     from oracle import pyoracle as po
     sc = po.Scene(arrays)
     prm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=0)
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or (os.cpu_count() or 1)))
-    n = 4096
+    n = min(len(src), 65536)
     t0 = time.perf_counter()
     _, _, st = sc.render(cam, src[:n].copy(), W, H, prm, 0, 1, threads=threads)
     dt = time.perf_counter() - t0
-    rate = (st.extend_rays + st.connect_rays) / max(dt, 1e-9)
-    per_source = (st.extend_rays + st.connect_rays) / n
-    n2 = int(min(len(src), max(n, target_seconds * rate / max(per_source, 1e-9))))
+    pilot_rays = st.extend_rays + st.connect_rays
+    rate = pilot_rays / max(dt, 1e-9)
+    want_rays = target_seconds * rate
+    rays_per_source_spp = pilot_rays / n
+    n2 = int(min(len(src), max(n, want_rays / max(rays_per_source_spp, 1e-9))))
+    spp = int(max(1, min(64, round(want_rays / max(rays_per_source_spp * n2, 1e-9)))))
     t0 = time.perf_counter()
-    _, _, st = sc.render(cam, src[:n2].copy(), W, H, prm, 0, 1, threads=threads)
+    _, _, st = sc.render(cam, src[:n2].copy(), W, H, prm, 0, spp, threads=threads)
     dt = time.perf_counter() - t0
     rays = st.extend_rays + st.connect_rays
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"first {n2} of {len(src)} sample sources of the same workload, 1 spp, {rays} rays in {dt:.2f} s"}
+            "sample": f"first {n2} of {len(src)} sample sources of the same workload, {spp} spp, {rays} rays in {dt:.2f} s"}
 
 
 def main():
@@ -207,8 +211,8 @@ def main():
             "spp_per_s": samples / (W * H) / elapsed,
             "rays": rays,
             "reduce_ms": reduce_s * 1e3,
-            "kernel_ms": {"extend": st.extend_ms, "shade": st.shade_ms, "sample": st.sample_ms,
-                          "connect": st.connect_ms},
+            "kernel_ms": {"extend": st.extend_ms, "extend_finish": st.finish_ms, "shade": st.shade_ms,
+                          "sample": st.sample_ms, "connect": st.connect_ms},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
