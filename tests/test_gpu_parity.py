@@ -153,6 +153,31 @@ def test_per_material_kernels_and_connect_rays_config5_small(pt, config_scenes):
     assert ffi.MAT_METALLIC in arrays2["classic_refs"]["kind"].tolist()
 
 
+def test_shadow_ray_sets_any_hit_ids(pt, config_scenes):
+    # the connect (shadow) rays of configuration 5's scene at bounces 1 and 2, as
+    # the oracle's per-material path generates them, traced as any-hit queries:
+    # occlusion flag, first accepted triangle, t bits and visit counts
+    arrays, info = config_scenes(5, dragon_n_u=96, dragon_n_v=24)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    W, H = 160, 90
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    oprm = po.default_params(max_bounces=8, seed=info.seed, shade_mode=1, nee=1)
+    total = 0
+    for bounce in (1, 2):
+        rays, tmax = sc.connect_rays(cam, src, W, H, oprm, 0, bounce)
+        assert len(rays) > 500
+        total += len(rays)
+        want, wc = sc.trace_any(rays, tmax, want_counts=True)
+        got, gc = pt.trace_any(rays, tmax, want_counts=True)
+        assert hits_equal(got, want)
+        assert gc.as_dict() == wc.as_dict()
+        occluded = want["instance_id"] != ffi.NO_HIT
+        assert 0 < occluded.sum() < len(rays)  # both outcomes occur
+    assert total > 2000
+
+
 def test_config1_full_render_and_pixels(pt, config_scenes):
     # configuration 1 in full: suzanne + light, 256x256, 1 spp, 4 bounces
     arrays, info = config_scenes(1)
