@@ -9,13 +9,10 @@
 // ascending index, a hit with t2 == t replaces the previous one; the TLAS box
 // test also rejects boxes entirely behind the ray, the BLAS one does not.
 //
-// What differs from the shader is scheduling:
+// What differs from the shader is scheduling (details at trace_engine):
 //   - the nested do-while loops are flattened into per-lane state machines
-//     driven by ONE wave-uniform loop, so lanes in different instances or at
-//     different depths run the same instructions;
-//   - a lane that reaches a leaf parks it; parked leaves are tested together
-//     in a separate phase (node steps and triangle tests are not interleaved
-//     at one-lane utilisation);
+//     driven by ONE wave-uniform loop, so lanes in different instances, at
+//     different depths, on nodes or on triangles run the same instructions;
 //   - a leaf with kCoopLeaf or more triangles (the builder leaves such leaves
 //     behind when its partition puts everything on one side) is tested by the
 //     whole wave, 64 triangles per step, for the lane that reached it.  A scan
@@ -24,8 +21,8 @@
 //     that with a min-reduction on (t2, -index); u, v, t2 of a triangle do not
 //     depend on the current t, so the bits match;
 //   - rays differ wildly in cost, so a wave does not wait for its slowest ray:
-//     when fewer than kRefillBelow lanes are still walking, finished lanes hand
-//     their results over and pull new rays (wave-uniform refill point).
+//     waves are persistent, finished lanes hand their results over and pull new
+//     rays at wave-uniform service points.
 #pragma once
 
 #include <float.h>
@@ -40,9 +37,6 @@ namespace mirt {
 #endif
 #ifndef MIRT_REFILL_BELOW
 #define MIRT_REFILL_BELOW 40
-#endif
-#ifndef MIRT_NODE_BURST
-#define MIRT_NODE_BURST 8
 #endif
 constexpr uint32_t kCoopLeaf = MIRT_COOP_LEAF;
 constexpr int kRefillBelow = MIRT_REFILL_BELOW;  // refill when fewer lanes than this are walking
