@@ -501,12 +501,17 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
   hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, st, fp);
 }
 
+constexpr int kEngineBlocksPerCU = 5;
+
 int trace_grid_blocks(int num_cus) {
   static int per_cu = 0;
   if (per_cu == 0) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, 256, 0) != hipSuccess || n < 1) n = 4;
-    per_cu = n > 8 ? 8 : n;
+    // The engine is bound by instruction issue, which three to four waves per
+    // SIMD saturate; more resident waves only mean fewer rays per wave and a
+    // longer drain, so the grid stops at kEngineBlocksPerCU blocks per CU.
+    per_cu = n > kEngineBlocksPerCU ? kEngineBlocksPerCU : n;
   }
   return per_cu * num_cus;
 }
