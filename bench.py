@@ -175,7 +175,7 @@ def main():
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("workload") == f"config{args.config} {W}x{H}":
+                if tj.get("workload") == f"config{args.config} {W}x{H}" and tj.get("paths_in_flight") == n_paths:
                     traffic = tj.get("hbm_bytes_per_extend_launch")
             except Exception:
                 traffic = None
