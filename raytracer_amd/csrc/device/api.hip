@@ -366,12 +366,13 @@ void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_samp
   const DFrameParams fp = frame_params(c, sample_limit, first_sample);
   timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
-  timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
   if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
+    timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
     if (c->params.nee && fp.have_lights) timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
     timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
   } else {
-    timed_launch(c, K_SHADE, [&] { launch_shade_uber(cfg, c->sc, c->st, fp); });
+    // uber shading: the extend epilogue and the shade kernel are one launch
+    timed_launch(c, K_SHADE, [&] { launch_finish_shade_uber(cfg, c->sc, c->st, fp); });
   }
   c->frame++;
   c->frames_total++;

@@ -14,7 +14,7 @@ namespace mirt {
 // later kernel that neither pops nor pushes it, so no kernel ever pushes and
 // pops the same queue (the reference keeps that invariant too).
 enum QueueId {
-  Q_TERM0 = 0, Q_TERM1, Q_EXT0, Q_EXT1, Q_SHADE, Q_CONNECT, Q_LAMBERTIAN, Q_METALLIC, Q_DIELECTRIC, Q_EMISSIVE,
+  Q_TERM0 = 0, Q_TERM1, Q_EXT0, Q_EXT1, Q_CONNECT, Q_LAMBERTIAN, Q_METALLIC, Q_DIELECTRIC, Q_EMISSIVE,
   Q_COUNT,
   // work cursors of the two ray-tracing kernels (chunks handed to waves), kept
   // in the same counter array and cleared by the sample kernel every frame
@@ -68,8 +68,10 @@ int trace_grid_blocks(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// per-material shading: the extend epilogue (hit records, bounce count, routing to the material queues)
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
-void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// uber shading: the extend epilogue and shadeMain in one kernel
+void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);

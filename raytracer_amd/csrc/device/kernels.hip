@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
     // clear the counters of the queues that are idle during this kernel
     st.qcount[Q_TERM0 + (par ^ 1u)] = 0u;
     st.qcount[Q_EXT0 + (par ^ 1u)] = 0u;
-    st.qcount[Q_SHADE] = 0u;
     st.qcount[Q_CONNECT] = 0u;
     st.qcount[Q_LAMBERTIAN] = 0u;
     st.qcount[Q_METALLIC] = 0u;
@@ -186,12 +185,13 @@ __global__ __launch_bounds__(256, MIRT_EXTEND_WAVES) void k_extend(DScene sc, DS
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
 }
 
-// extensionMain's epilogue (shaders/ray_extend.slang:34-50), one thread per
-// entry of the extension queue: a miss adds the sky and ends the path, a hit
-// gets its world-space record and goes to the shading queue(s).
-template <bool CLASSIC>
+// The extend epilogue of per-material shading (shaders/ray_extend.slang:34-50
+// with the bounce count and routing of archive/extension.slang:94-101), one
+// thread per entry of the extension queue: a miss adds the sky and ends the
+// path, a hit gets its world-space record and goes to the connect queue or to
+// the queue of its material.  (Uber shading does this inside
+// k_finish_shade_uber.)
 __global__ __launch_bounds__(256) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
-  __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_extend_finish(DScene sc, DState st, DFr
     const bool fin = i < count;
     uint32_t slot = 0;
     bool hit = false;
-    uint32_t route = 0;  // classic: queue of the hit material
+    uint32_t route = 0;  // queue of the hit material
     if (fin) {
       slot = ext[i];
       DPath *pp = st.path + slot;
@@ -234,33 +234,27 @@ __global__ __launch_bounds__(256) void k_extend_finish(DScene sc, DState st, DFr
         finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
         h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
         h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
-        if (CLASSIC) {
-          // archive/extension.slang:94-101: a hit costs one bounce; out of
-          // bounces means terminate without shading
-          uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
-          const uint32_t bounces = *pb - 1u;
-          *pb = bounces;
-          if (bounces == 0u) {
-            hit = false;
-          } else if (fp.p.nee && fp.have_lights) {
-            route = Q_CONNECT;
-          } else {
-            route = Q_LAMBERTIAN - 1u + sc.inst[best.inst].kind;
-            if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
-          }
+        // archive/extension.slang:94-101: a hit costs one bounce; out of
+        // bounces means terminate without shading
+        uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
+        const uint32_t bounces = *pb - 1u;
+        *pb = bounces;
+        if (bounces == 0u) {
+          hit = false;
+        } else if (fp.p.nee && fp.have_lights) {
+          route = Q_CONNECT;
+        } else {
+          route = Q_LAMBERTIAN - 1u + sc.inst[best.inst].kind;
+          if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
         }
       }
     }
-    if (!CLASSIC) {
-      block_push2(sh, term_cnt, term, fin && !hit, &st.qcount[Q_SHADE], st.qdata[Q_SHADE], hit, slot);
-    } else {
-      wave_push(term_cnt, term, fin && !hit, slot);
-      wave_push(&st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], hit && route == Q_CONNECT, slot);
-      wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], hit && route == Q_LAMBERTIAN, slot);
-      wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], hit && route == Q_METALLIC, slot);
-      wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
-      wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
-    }
+    wave_push(term_cnt, term, fin && !hit, slot);
+    wave_push(&st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], hit && route == Q_CONNECT, slot);
+    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], hit && route == Q_LAMBERTIAN, slot);
+    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], hit && route == Q_METALLIC, slot);
+    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
+    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
   }
 }
 
@@ -354,61 +348,92 @@ __device__ __forceinline__ v3 material_brdf(v3 wi, v3 wo, v3 n, const DMaterial 
   return mix3(dielectric, metallic, m.metallic);
 }
 
-__global__ __launch_bounds__(256) void k_shade_uber(DScene sc, DState st, DFrameParams fp) {
+// shadeMain (shaders/shade.slang:143-224) for one slot whose hit record is
+// given in registers: emission, the three sampling draws, throughput update,
+// the bounce ray.  Returns whether the path goes on.
+__device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &st, uint32_t slot, v3 wo, v3 hit_pos,
+                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim) {
+  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+  float4 pa = p4[0], pb = p4[1];
+  const float4 pr = p4[2];
+  Rng rng{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)};
+  const DMaterial mat = sc.mat[sc.inst[inst].material];
+
+  // s.rad += s.throughput * mat.emissive.rgb
+  pa.x = pa.x + pb.x * mat.emissive[0];
+  pa.y = pa.y + pb.y * mat.emissive[1];
+  pa.z = pa.z + pb.z * mat.emissive[2];
+  const float sgn = ff != 0u ? 1.0f : -1.0f;
+  const v3 n = V3(hit_n.x * sgn, hit_n.y * sgn, hit_n.z * sgn);
+
+  cosine_hemisphere_draws(rng);   // diffuse_sample: value unused, draws kept
+  unit_sphere_sample_draws(rng);  // metallicSample -> unitSphereSample
+  const v3 wi = cosine_hemisphere_sample(n, rng);
+  const float pdf = __builtin_fabsf(dot3(wi, n)) / kPi;
+  const v3 brdf = material_brdf(wi, wo, n, mat);
+  const float ndotwi = __builtin_fabsf(dot3(n, wi));
+  pb.x = pb.x * (brdf.x * ndotwi * 1.0f / pdf);
+  pb.y = pb.y * (brdf.y * ndotwi * 1.0f / pdf);
+  pb.z = pb.z * (brdf.z * ndotwi * 1.0f / pdf);
+  const uint32_t bounces = __float_as_uint(pa.w) - 1u;
+  pa.w = __uint_as_float(bounces);
+  p4[0] = pa;
+  p4[1] = pb;
+  p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+  // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just
+  // hit is excluded from the next traversal instead
+  store_ray(st.ray, slot, hit_pos, wi, inst, prim);
+  return bounces != 0u;
+}
+
+// extensionMain's epilogue and shadeMain in one pass over the extension queue
+// (uber shading): the hit record stays in registers between the two, a miss
+// adds the sky and ends the path.
+__global__ __launch_bounds__(256) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
-  const uint32_t *shq = st.qdata[Q_SHADE];
-  const uint32_t count = st.qcount[Q_SHADE];
-  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+  const uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_EXT0 + par];
+  unsigned long long shaded = 0;
+  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
     bool alive = false;
     if (active) {
-      slot = shq[i];
-      float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
-      float4 pa = p4[0], pb = p4[1];
-      const float4 pr = p4[2];
-      Rng rng{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)};
-      v3 rpos, wo;
-      uint32_t li, lp;
-      load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
+      slot = ext[i];
       const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
-      const float4 ha = h4[0], hb = h4[1];
-      const uint32_t inst_ff = __float_as_uint(ha.w);
-      const uint32_t inst = inst_ff & 0x7FFFFFFFu, ff = inst_ff >> 31, prim = __float_as_uint(hb.w);
-      const DMaterial mat = sc.mat[sc.inst[inst].material];
-
-      // s.rad += s.throughput * mat.emissive.rgb
-      pa.x = pa.x + pb.x * mat.emissive[0];
-      pa.y = pa.y + pb.y * mat.emissive[1];
-      pa.z = pa.z + pb.z * mat.emissive[2];
-      const float sgn = ff != 0u ? 1.0f : -1.0f;
-      const v3 n = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
-
-      cosine_hemisphere_draws(rng);   // diffuse_sample: value unused, draws kept
-      unit_sphere_sample_draws(rng);  // metallicSample -> unitSphereSample
-      const v3 wi = cosine_hemisphere_sample(n, rng);
-      const float pdf = __builtin_fabsf(dot3(wi, n)) / kPi;
-      const v3 brdf = material_brdf(wi, wo, n, mat);
-      const float ndotwi = __builtin_fabsf(dot3(n, wi));
-      pb.x = pb.x * (brdf.x * ndotwi * 1.0f / pdf);
-      pb.y = pb.y * (brdf.y * ndotwi * 1.0f / pdf);
-      pb.z = pb.z * (brdf.z * ndotwi * 1.0f / pdf);
-      const uint32_t bounces = __float_as_uint(pa.w) - 1u;
-      pa.w = __uint_as_float(bounces);
-      alive = bounces != 0u;
-      p4[0] = pa;
-      p4[1] = pb;
-      p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
-      // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just
-      // hit is excluded from the next traversal instead
-      store_ray(st.ray, slot, V3(ha.x, ha.y, ha.z), wi, inst, prim);
+      const float4 raw = h4[0];
+      BestHit best;
+      best.u = raw.x;
+      best.v = raw.y;
+      best.t = raw.z;
+      best.inst = __float_as_uint(raw.w);
+      if (best.inst == kMissInst) {
+        // rad += throughput * sky
+        float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+        float4 a = p4[0];
+        const float4 b = p4[1];
+        const float sky = fp.p.sky_radiance;
+        a.x = a.x + b.x * sky;
+        a.y = a.y + b.y * sky;
+        a.z = a.z + b.z * sky;
+        p4[0] = a;
+      } else {
+        best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
+        v3 rpos, wo, hp, hn;
+        uint32_t li, lp, ff;
+        load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
+        finish_hit(sc, wo, best, hp, hn, ff);
+        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim);
+        shaded++;
+      }
     }
     block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
                 &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)count);
+  for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
+  if (lane_id() == 0u && shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
 }
 
 // --------------------------------------------------------------- resolve
@@ -523,15 +548,11 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  const dim3 grid(cfg.grid_blocks);
-  if (fp.p.shade_mode == MIRT_SHADE_CLASSIC)
-    hipLaunchKernelGGL((k_extend_finish<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-  else
-    hipLaunchKernelGGL((k_extend_finish<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL(k_extend_finish, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
 }
 
-void launch_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_shade_uber, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  hipLaunchKernelGGL(k_finish_shade_uber, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {
