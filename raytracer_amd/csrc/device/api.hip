@@ -294,8 +294,8 @@ int get_ctx_device(mirt_ctx *c) {
 LaunchCfg launch_cfg(mirt_ctx *c) {
   LaunchCfg cfg;
   cfg.stream = c->stream;
-  uint32_t want = c->have_state ? (c->st.slots + 255u) / 256u : 1u;
-  uint32_t cap = (uint32_t)c->num_cus * 8u;
+  uint32_t want = c->have_state ? (c->st.slots + kStreamBlock - 1u) / kStreamBlock : 1u;
+  uint32_t cap = (uint32_t)c->num_cus * 2u;  // two 1024-thread blocks fill a CU's 32 wave slots
   cfg.grid_blocks = (int)(want < cap ? (want ? want : 1u) : cap);
   cfg.num_cus = c->num_cus;
   return cfg;
@@ -831,7 +831,7 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
   if (e != hipSuccess) { free_all(tmp); return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e)); }
   LaunchCfg cfg;
   cfg.stream = ctx->stream;
-  cfg.grid_blocks = ctx->num_cus * 8;
+  cfg.grid_blocks = ctx->num_cus * 2;
   cfg.num_cus = ctx->num_cus;
   uint32_t *work = reinterpret_cast<uint32_t *>(ctx->d_trace_counts + 5);  // chunk cursor, zeroed before every launch
   if (ms_per_launch) {

@@ -182,14 +182,14 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
 // Common frame of the four kernels: pop `queue`, shade, push to the next
 // frame's extension queue (alive) or terminate queue.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_material(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const int q = Q_LAMBERTIAN - 1 + KIND;
   const uint32_t *mq = st.qdata[q];
   const uint32_t count = st.qcount[q];
   const bool use_shadow = fp.p.nee != 0u && fp.have_lights != 0u;
-  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
@@ -317,10 +317,10 @@ void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, co
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   // the four per-material kernels, one queue each (archive frame order:
   // src/app.rs:402-410 dispatches every material phase each frame)
-  hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE>), dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 }  // namespace mirt

@@ -31,34 +31,46 @@ __device__ __forceinline__ void wave_push(uint32_t *count, uint32_t *data, bool 
   if (pred) data[base + rank_in_mask(mask)] = value;
 }
 
-// Block-aggregated push to two queues at once for 256-thread blocks: the four
-// waves' ballot counts meet in LDS, threads 0 and 1 reserve the two queue
-// tails with one atomic each.  Must be reached by every thread of the block.
+// Block-aggregated push to two queues at once, for blocks of up to 1024
+// threads: the waves' ballot counts meet in LDS, the first wave turns them into
+// offsets with a 16-lane scan per queue and reserves the two queue tails with
+// one atomic each.  Queue counters are single words that every block of a
+// kernel adds to, and same-address atomics are served one after the other
+// (about 15 ns apiece on MI355X), so the streaming kernels run 1024-thread
+// blocks: one atomic per queue per 1024 entries.  Must be reached by every
+// thread of the block.
 struct BlockPush2 {
-  uint32_t wave_cnt[2][4];
-  uint32_t base[2];
+  uint32_t cnt[2][16];
+  uint32_t off[2][16];
 };
 __device__ __forceinline__ void block_push2(BlockPush2 &sh, uint32_t *count0, uint32_t *data0, bool pred0,
                                             uint32_t *count1, uint32_t *data1, bool pred1, uint32_t value) {
-  const uint32_t tid = threadIdx.x, wid = tid >> 6;
+  const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+  const uint32_t n_waves = (blockDim.x + 63u) >> 6;
   const unsigned long long m0 = __ballot(pred0), m1 = __ballot(pred1);
-  if ((tid & 63u) == 0u) {
-    sh.wave_cnt[0][wid] = (uint32_t)__popcll(m0);
-    sh.wave_cnt[1][wid] = (uint32_t)__popcll(m1);
+  if (lane == 0u) {
+    sh.cnt[0][wid] = (uint32_t)__popcll(m0);
+    sh.cnt[1][wid] = (uint32_t)__popcll(m1);
   }
   __syncthreads();
-  if (tid < 2u) {
-    const uint32_t total = sh.wave_cnt[tid][0] + sh.wave_cnt[tid][1] + sh.wave_cnt[tid][2] + sh.wave_cnt[tid][3];
-    sh.base[tid] = total ? atomicAdd(tid == 0u ? count0 : count1, total) : 0u;
+  if (wid == 0u) {
+    // lanes 0..15: queue 0, lanes 16..31: queue 1; one wave's count per lane
+    const uint32_t q = (lane >> 4) & 1u, w = lane & 15u;
+    const uint32_t c = (lane < 32u && w < n_waves) ? sh.cnt[q][w] : 0u;
+    uint32_t x = c;  // inclusive scan within the 16-lane group
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, d, 16);
+      if (w >= (uint32_t)d) x += y;
+    }
+    uint32_t base = 0u;
+    if (lane == 15u && x != 0u) base = atomicAdd(count0, x);
+    if (lane == 31u && x != 0u) base = atomicAdd(count1, x);
+    base = (uint32_t)__shfl((int)base, 15, 16);
+    if (lane < 32u && w < n_waves) sh.off[q][w] = base + x - c;
   }
   __syncthreads();
-  uint32_t off0 = sh.base[0], off1 = sh.base[1];
-  for (uint32_t w = 0; w < wid; ++w) {
-    off0 += sh.wave_cnt[0][w];
-    off1 += sh.wave_cnt[1][w];
-  }
-  if (pred0) data0[off0 + rank_in_mask(m0)] = value;
-  if (pred1) data1[off1 + rank_in_mask(m1)] = value;
+  if (pred0) data0[sh.off[0][wid] + rank_in_mask(m0)] = value;
+  if (pred1) data1[sh.off[1][wid] + rank_in_mask(m1)] = value;
   __syncthreads();
 }
 

@@ -56,9 +56,12 @@ struct DFrameParams {
   uint32_t counting;
 };
 
+// Threads per block of the streaming frame kernels (see block_push2).
+constexpr unsigned kStreamBlock = 1024;
+
 struct LaunchCfg {
   hipStream_t stream;
-  int grid_blocks;  // blocks of 256 threads for the streaming frame kernels
+  int grid_blocks;  // blocks of kStreamBlock threads for the streaming frame kernels
   int num_cus;      // the ray-tracing kernels launch a persistent grid sized from this
 };
 

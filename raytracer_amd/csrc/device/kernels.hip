@@ -14,8 +14,8 @@
 // global thread i (grid-stride), because no kernel pushes the queue it pops.
 // Pushing compacts with wave64 ballots: a wave counts its pushing lanes with
 // one ballot, ranks them with mbcnt, and reserves its slice of the tail with a
-// single atomic; the cheap uniform kernels first combine their four waves'
-// counts in LDS so that a 256-thread block issues one atomic per queue.
+// single atomic; the streaming kernels first combine their sixteen waves'
+// counts in LDS so that a 1024-thread block issues one atomic per queue.
 #include <float.h>
 
 #include "kernels.h"
@@ -37,8 +37,9 @@ __device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
   return (uint32_t)x;
 }
 
-__global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
+  __shared__ unsigned long long sh_sample_base;
   const uint32_t par = fp.frame & 1u;
   const uint32_t *term = st.qdata[Q_TERM0 + par];
   uint32_t *ext = st.qdata[Q_EXT0 + par];
@@ -52,8 +53,19 @@ __global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
   const float dx = cam.dims[0], dy = cam.dims[1];
   const v3 top_left = sub3(add3(scale3(fwd, cam.focal_length), scale3(up, dy)), scale3(right, dx));
 
+  // The block reserves the sample numbers of all its entries with one atomic:
+  // its grid-stride rounds cover full blocks of entries except the last one.
+  const uint32_t bs = blockDim.x, stride = gridDim.x * bs;
+  if (threadIdx.x == 0u) {
+    unsigned long long mine = 0;
+    for (uint32_t base = blockIdx.x * bs; base < count; base += stride) mine += count - base < bs ? count - base : bs;
+    sh_sample_base = mine ? atomicAdd(st.sample_index, mine) : 0ull;
+  }
+  __syncthreads();
+  unsigned long long next_sample = sh_sample_base;
+
   unsigned long long finished = 0, spawned = 0;
-  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+  for (uint32_t base = blockIdx.x * bs; base < count; base += stride) {
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
@@ -64,23 +76,18 @@ __global__ __launch_bounds__(256) void k_sample(DState st, DFrameParams fp) {
       const float4 a = reinterpret_cast<const float4 *>(pp)[0];
       const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
       if (source != kNoSample) {
+#ifndef MIRT_EXPERIMENT_NO_ACCUM
         atomicAdd(&st.count[source], 1u);
         atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(a.x, fp.p.fixed_point_scale));
         atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(a.y, fp.p.fixed_point_scale));
         atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(a.z, fp.p.fixed_point_scale));
+#endif
         finished++;
       }
     }
-    // pull the next sample (shaders/sample.slang:64-68): one atomic per wave
-    const unsigned long long mask = __ballot(active);
-    unsigned long long si = ~0ull;
-    if (mask) {
-      const int leader = __ffsll((long long)mask) - 1;
-      unsigned long long b = 0;
-      if ((int)lane_id() == leader) b = atomicAdd(st.sample_index, (unsigned long long)__popcll(mask));
-      b = __shfl(b, leader);
-      si = b + rank_in_mask(mask);
-    }
+    // pull the next sample (shaders/sample.slang:64-68) from the block's reservation
+    const unsigned long long si = next_sample + threadIdx.x;
+    next_sample += bs;
     const bool spawn = active && si < fp.sample_limit;
     if (spawn) {
       uint32_t source, k;
@@ -191,14 +198,14 @@ __global__ __launch_bounds__(256, MIRT_EXTEND_WAVES) void k_extend(DScene sc, DS
 // path, a hit gets its world-space record and goes to the connect queue or to
 // the queue of its material.  (Uber shading does this inside
 // k_finish_shade_uber.)
-__global__ __launch_bounds__(256) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
   uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
   uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
-  const uint32_t stride = gridDim.x * 256u;
-  for (uint32_t base = blockIdx.x * 256u; base < count; base += stride) {  // uniform per block
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
     const bool fin = i < count;
     uint32_t slot = 0;
@@ -389,13 +396,13 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &
 // extensionMain's epilogue and shadeMain in one pass over the extension queue
 // (uber shading): the hit record stays in registers between the two, a miss
 // adds the sky and ends the path.
-__global__ __launch_bounds__(256) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
   unsigned long long shaded = 0;
-  for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {  // uniform per block
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
@@ -523,7 +530,7 @@ void launch_init_slots(const LaunchCfg &cfg, const DState &st) {
 }
 
 void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, st, fp);
+  hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, st, fp);
 }
 
 constexpr int kEngineBlocksPerCU = 5;
@@ -548,11 +555,11 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_extend_finish, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL(k_extend_finish, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_finish_shade_uber, dim3(cfg.grid_blocks), dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL(k_finish_shade_uber, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {
