@@ -36,6 +36,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SCENES = {1: "suzanne under a rect light",
+          2: "open Cornell box + Lambertian/Metallic/Dielectric teapots",
+          3: "simple_scene (open Cornell box + dragon)",
+          4: "10x10x10 grid of dragon/teapot/suzanne/cube instances",
+          5: "Cornell box with ceiling light + dielectric dragon, light sampling"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
@@ -204,7 +209,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"config{args.config}: simple_scene (open Cornell box + dragon) {W}x{H}, "
+            "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, "
                                    f"{info.max_bounces} bounces, {spp_step} spp per step per GPU, "
                                    f"{'per-material' if info.shade_mode else 'uber'} shading",
                        "geometry": geometry, "paths_in_flight": n_paths, "parallelism": f"spp split x{world}"},

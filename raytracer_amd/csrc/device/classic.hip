@@ -81,7 +81,6 @@ __device__ __forceinline__ float lambert_pdf(v3 wi, v3 n) { return fmax_nn(0.0f,
 // slot to the queue of its hit material.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFrameParams fp) {
-  const uint32_t par = fp.frame & 1u;
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
   LaneCounts lc;
@@ -143,15 +142,41 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
     r.payload = slot;
     if (shoot) traced++;
   };
+  // the verdict joins what fetch parked; k_connect_finish does the rest
   auto finish = [&](bool fin, uint32_t slot, bool occluded, float, const BestHit &) {
-    uint32_t kind = 0xFFFFFFFFu;
-    if (fin) {
+    if (fin) reinterpret_cast<float *>(st.shadow + slot)[7] = occluded ? 1.0f : 0.0f;
+  };
+  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, nullptr}, lc, fetch, finish);
+  if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
+  for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
+  if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
+}
+
+// The epilogue of shadowMain (archive/shadow.slang:122-139), one thread per
+// entry of the connect queue: the slot's ShadowData from the parked sample and
+// the any-hit verdict, then the slot goes to the queue of its hit material.
+__global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DState st, DFrameParams fp) {
+  // queues 0..3: the four material queues in QueueId order; 4: terminate
+  __shared__ BlockPushN<5> sh;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *cq = st.qdata[Q_CONNECT];
+  const uint32_t count = st.qcount[Q_CONNECT];
+  uint32_t *const counts[5] = {&st.qcount[Q_LAMBERTIAN], &st.qcount[Q_METALLIC], &st.qcount[Q_DIELECTRIC],
+                               &st.qcount[Q_EMISSIVE], &st.qcount[Q_TERM0 + (par ^ 1u)]};
+  uint32_t *const datas[5] = {st.qdata[Q_LAMBERTIAN], st.qdata[Q_METALLIC], st.qdata[Q_DIELECTRIC],
+                              st.qdata[Q_EMISSIVE], st.qdata[Q_TERM0 + (par ^ 1u)]};
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {  // uniform per block
+    const uint32_t i = base + threadIdx.x;
+    int route = -1;
+    uint32_t slot = 0;
+    if (i < count) {
+      slot = cq[i];
       float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
       float4 s0 = sh4[0];
-      const float4 parked = sh4[1];
+      const float4 parked = sh4[1];  // light instance, shoot flag, light triangle, occluded flag
       const uint32_t light_inst = __float_as_uint(parked.x);
       float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (parked.y != 0.0f && !occluded) {
+      if (parked.y != 0.0f && parked.w == 0.0f) {
         const DInst *linst = &sc.inst[light_inst];
         if (linst->kind == MIRT_MAT_EMISSIVE) {
           const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
@@ -163,19 +188,12 @@ __global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFramePar
       sh4[0] = s0;
       sh4[1] = s1;
       const uint32_t inst_ff = __float_as_uint(reinterpret_cast<const float4 *>(st.hit + slot)[0].w);
-      kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
+      const uint32_t kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
+      // no material (archive/logic.slang:171-174): the path ends here
+      route = kind == MIRT_MAT_NONE ? 4 : (int)kind - (int)MIRT_MAT_LAMBERTIAN;
     }
-    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], kind == MIRT_MAT_LAMBERTIAN, slot);
-    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], kind == MIRT_MAT_METALLIC, slot);
-    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], kind == MIRT_MAT_DIELECTRIC, slot);
-    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], kind == MIRT_MAT_EMISSIVE, slot);
-    // no material (archive/logic.slang:171-174): the path ends here
-    wave_push(&st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], kind == MIRT_MAT_NONE, slot);
-  };
-  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, nullptr}, lc, fetch, finish);
-  if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
-  for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
-  if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
+    block_push_n<5>(sh, counts, datas, route, slot);
+  }
 }
 
 // ------------------------------------------------------- material kernels
@@ -312,6 +330,7 @@ void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, co
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
   else hipLaunchKernelGGL((k_connect<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL(k_connect_finish, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

@@ -74,6 +74,50 @@ __device__ __forceinline__ void block_push2(BlockPush2 &sh, uint32_t *count0, ui
   __syncthreads();
 }
 
+// The same for a thread that pushes to at most one of N queues (`route` in
+// [0, N), or negative for none): one atomic per queue per block.
+template <int N>
+struct BlockPushN {
+  uint32_t cnt[N][16];
+  uint32_t off[N][16];
+};
+template <int N>
+__device__ __forceinline__ void block_push_n(BlockPushN<N> &sh, uint32_t *const (&count)[N], uint32_t *const (&data)[N],
+                                             int route, uint32_t value) {
+  const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+  const uint32_t n_waves = (blockDim.x + 63u) >> 6;
+  unsigned long long mine = 0ull;  // the ballot of this thread's queue
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const unsigned long long m = __ballot(route == q);
+    if (lane == 0u) sh.cnt[q][wid] = (uint32_t)__popcll(m);
+    if (route == q) mine = m;
+  }
+  __syncthreads();
+  if (wid == 0u) {
+    // four queues at a time: 16 lanes scan the 16 waves' counts of one queue
+#pragma unroll
+    for (int q0 = 0; q0 < N; q0 += 4) {
+      const int q = q0 + (int)(lane >> 4);
+      const uint32_t w = lane & 15u;
+      const bool live = q < N && w < n_waves;
+      const uint32_t c = live ? sh.cnt[q < N ? q : 0][w] : 0u;
+      uint32_t x = c;  // inclusive scan within the 16-lane group
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)x, d, 16);
+        if (w >= (uint32_t)d) x += y;
+      }
+      uint32_t base = 0u;
+      if (w == 15u && q < N && x != 0u) base = atomicAdd(count[q < N ? q : 0], x);
+      base = (uint32_t)__shfl((int)base, 15, 16);
+      if (live) sh.off[q][w] = base + x - c;
+    }
+  }
+  __syncthreads();
+  if (route >= 0) data[route][sh.off[route][wid] + rank_in_mask(mine)] = value;
+  __syncthreads();
+}
+
 __device__ __forceinline__ void load_ray(const DRay *rays, uint32_t i, v3 &pos, v3 &dir, uint32_t &last_inst,
                                          uint32_t &last_prim) {
   const float4 *r4 = reinterpret_cast<const float4 *>(rays + i);

@@ -204,6 +204,13 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
   const uint32_t count = st.qcount[Q_EXT0 + par];
   uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
   uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
+  // queue 0: terminate; 1..5: connect and the four material queues, in QueueId order
+  __shared__ BlockPushN<6> sh;
+  static_assert(Q_LAMBERTIAN == Q_CONNECT + 1 && Q_EMISSIVE == Q_CONNECT + 4, "routes index consecutive queues");
+  uint32_t *const counts[6] = {term_cnt, &st.qcount[Q_CONNECT], &st.qcount[Q_LAMBERTIAN], &st.qcount[Q_METALLIC],
+                               &st.qcount[Q_DIELECTRIC], &st.qcount[Q_EMISSIVE]};
+  uint32_t *const datas[6] = {term, st.qdata[Q_CONNECT], st.qdata[Q_LAMBERTIAN], st.qdata[Q_METALLIC],
+                              st.qdata[Q_DIELECTRIC], st.qdata[Q_EMISSIVE]};
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
@@ -256,12 +263,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
         }
       }
     }
-    wave_push(term_cnt, term, fin && !hit, slot);
-    wave_push(&st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], hit && route == Q_CONNECT, slot);
-    wave_push(&st.qcount[Q_LAMBERTIAN], st.qdata[Q_LAMBERTIAN], hit && route == Q_LAMBERTIAN, slot);
-    wave_push(&st.qcount[Q_METALLIC], st.qdata[Q_METALLIC], hit && route == Q_METALLIC, slot);
-    wave_push(&st.qcount[Q_DIELECTRIC], st.qdata[Q_DIELECTRIC], hit && route == Q_DIELECTRIC, slot);
-    wave_push(&st.qcount[Q_EMISSIVE], st.qdata[Q_EMISSIVE], hit && route == Q_EMISSIVE, slot);
+    const int r = !fin ? -1 : (!hit ? 0 : (int)(route - Q_CONNECT) + 1);
+    block_push_n<6>(sh, counts, datas, r, slot);
   }
 }
 
