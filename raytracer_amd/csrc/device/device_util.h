@@ -18,21 +18,9 @@ __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Wave-aggregated push: one ballot, one atomic per wave per queue, lanes
-// ranked with mbcnt.  Must be reached by every lane of the wave.
-__device__ __forceinline__ void wave_push(uint32_t *count, uint32_t *data, bool pred, uint32_t value) {
-  const unsigned long long mask = __ballot(pred);
-  if (mask == 0ull) return;
-  const uint32_t n = (uint32_t)__popcll(mask);
-  const int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane_id() == leader) base = atomicAdd(count, n);
-  base = (uint32_t)__shfl((int)base, leader);
-  if (pred) data[base + rank_in_mask(mask)] = value;
-}
-
 // Block-aggregated push to two queues at once, for blocks of up to 1024
-// threads: the waves' ballot counts meet in LDS, the first wave turns them into
+// threads: every wave counts its pushing lanes with one ballot and ranks them
+// with mbcnt, the waves' counts meet in LDS, the first wave turns them into
 // offsets with a 16-lane scan per queue and reserves the two queue tails with
 // one atomic each.  Queue counters are single words that every block of a
 // kernel adds to, and same-address atomics are served one after the other
