@@ -325,3 +325,36 @@ def test_full_size_properties_config3_1080p(pt, config_scenes):
     pt.render_spp(1)
     f4, fc = pt.read_accum()
     assert np.all(fc == 1) and np.all(f4.reshape(-1, 4)[:, :3] == 10000)
+
+
+def test_full_size_properties_per_material_path_1080p(pt, config_scenes):
+    # configuration 5's scene with the full-size dragon, per-material shading with
+    # light sampling, at 1080p: properties that need no full oracle run
+    arrays, info = config_scenes(5)
+    assert info.shade_mode == 1 and info.nee == 1
+    pt.upload_scene(arrays)
+    W, H = 1920, 1080
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
+    pt.create_state(W, H, 3 * W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(2)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == 2) and st.finished_samples == 2 * W * H == st.spawned_samples
+    # one connect ray at most per hit that is shaded, none without a hit
+    assert 0 < st.connect_rays <= st.shade_events <= st.extend_rays
+    # sample ranges add up and the result does not depend on the number of slots
+    pt.create_state(W, H, 500003, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(1)
+    pt.render_spp(1)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+    # a slice of it against the oracle: the first 2048 sources' sums
+    sc = po.Scene(arrays)
+    oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
+    w4, wc, _ = sc.render(cam, src[:2048].copy(), W, H, oprm, 0, 2)
+    assert np.array_equal(a4[: 4 * 2048], w4) and np.array_equal(ac[:2048], wc)
