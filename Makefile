@@ -3,6 +3,7 @@
 #   raytracer_amd/lib/libmirt.so       HIP kernels + C ABI for gfx950 (hipcc)
 #   raytracer_amd/lib/libmirt.a        the same objects as a static archive
 #   oracle/liboracle.so                CPU oracle (gcc) — test infrastructure only
+#   raytracer_amd/lib/render_c         examples/render_c.c, a plain-C user of the two ABIs
 #
 # Floating-point contract: no implicit contraction anywhere (-ffp-contract=off);
 # fused multiply-adds appear only where the source says fmaf(), correctly
@@ -25,11 +26,12 @@ DEV_FLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off \
               -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Wall -Iinclude
 ORACLE_FLAGS := -std=c11 -O2 -fPIC -ffp-contract=off -mfma -fopenmp -Wall -Wextra -Iinclude
 
-all: host device oracle
+all: host device oracle examples
 
 host: $(LIBDIR)/libmirt_host.so
 device: $(LIBDIR)/libmirt.so $(LIBDIR)/libmirt.a
 oracle: oracle/liboracle.so
+examples: $(LIBDIR)/render_c
 
 $(LIBDIR)/libmirt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -50,7 +52,11 @@ $(LIBDIR)/libmirt.a: $(DEV_OBJ)
 oracle/liboracle.so: oracle/oracle.c oracle/oracle_classic.inc oracle/oracle.h include/mirt.h
 	$(CC) $(ORACLE_FLAGS) -shared -o $@ oracle/oracle.c -lm
 
-clean:
-	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/*.a oracle/*.so
+# plain-C user of both ABIs (finds the libraries next to itself)
+$(LIBDIR)/render_c: examples/render_c.c include/mirt.h include/mirt_host.h $(LIBDIR)/libmirt.so $(LIBDIR)/libmirt_host.so
+	$(CC) -std=c11 -O2 -Wall -Wextra -Iinclude $< -L$(LIBDIR) -lmirt -lmirt_host -Wl,-rpath,'$$ORIGIN' -o $@
 
-.PHONY: all host device oracle clean
+clean:
+	rm -rf build $(LIBDIR)/*.so $(LIBDIR)/*.a $(LIBDIR)/render_c oracle/*.so
+
+.PHONY: all host device oracle examples clean

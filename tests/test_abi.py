@@ -63,6 +63,18 @@ def test_struct_sizes_match_the_reference_layouts():
     assert sizes[11] == C.sizeof(ffi.Params) and sizes[12] == C.sizeof(ffi.SceneDesc)
 
 
+def test_plain_c_example_builds_against_both_libraries(tmp_path):
+    # examples/render_c.c uses nothing but the two headers and links both libraries
+    exe = str(tmp_path / "render_c")
+    lib = os.path.join(ROOT, "raytracer_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "render_c.c"), "-L", lib, "-lmirt", "-lmirt_host",
+                           "-Wl,-rpath," + lib, "-o", exe])
+    # without arguments it prints its usage and touches no device
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
 def test_status_strings_and_default_params_need_no_device():
     L = ffi.device_lib()
     assert L.mirt_status_string(0) == b"ok"

@@ -358,3 +358,28 @@ def test_full_size_properties_per_material_path_1080p(pt, config_scenes):
     oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
     w4, wc, _ = sc.render(cam, src[:2048].copy(), W, H, oprm, 0, 2)
     assert np.array_equal(a4[: 4 * 2048], w4) and np.array_equal(ac[:2048], wc)
+
+
+def test_plain_c_driver_renders_the_same_sums(pt, config_scenes, tmp_path):
+    # examples/render_c.c (built by `make examples`) goes through both C ABIs from
+    # C: its checksum of the radiance sums must equal this process's render
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "lib", "render_c")
+    assert os.path.exists(exe), "run `make examples`"
+    assets = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    W, H, spp = 96, 64, 3
+    out = subprocess.run([exe, assets, "1", str(spp), str(tmp_path / "c.ppm"), str(W), str(H)], capture_output=True,
+                         text=True, timeout=100)
+    assert out.returncode == 0, out.stderr
+    words = out.stdout.split()
+    arrays, info = config_scenes(1)
+    pt.upload_scene(arrays)
+    src = host.make_sample_sources(W, H, info.seed)
+    pt.create_state(W, H, W * H, src, pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed))
+    pt.set_camera(host.default_camera(W, H))
+    pt.render_spp(spp)
+    s4, cnt = pt.read_accum()
+    want = int(s4.reshape(-1, 4)[:, :3].astype(np.uint64).sum())
+    assert int(words[1]) == want and int(words[3]) == int(cnt.sum()) == W * H * spp
+    ppm = open(tmp_path / "c.ppm", "rb").read()
+    assert ppm.startswith(b"P6\n96 64\n255\n") and len(ppm) == len(b"P6\n96 64\n255\n") + 3 * W * H
