@@ -258,6 +258,17 @@ void mirt_default_params(MirtParams *out);
  * HBM in the traversal layout. */
 int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *scene);
 
+/* Replaces the TLAS regeneration of binder_system when only transforms,
+ * instances, materials or lights changed (src/binder.rs:199-206,257-282): the
+ * caller passes the whole scene again and promises that the geometry arrays
+ * (geometry_offsets, vertices, indices, blas_nodes) are those of the last
+ * mirt_scene_upload; they are not read.  Instances, transforms, materials,
+ * TLAS nodes, tlas_to_instances, lights and the per-material tables are
+ * validated and replaced; nodes and triangles stay where they are in HBM.
+ * Falls back to a full upload if the number of geometries changed or the TLAS
+ * outgrew the room reserved for it. */
+int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *scene);
+
 /* Replaces PathtracerState::new (src/pathtracer_state.rs:96-353) and
  * PathtracerOutput::new (src/pathtracer.rs:56-122): allocates `threads` path
  * slots, the four queues, the accumulators for `n_sources` sample sources and

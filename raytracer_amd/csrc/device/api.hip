@@ -33,8 +33,11 @@ struct mirt_ctx {
   // scene
   bool have_scene = false;
   DScene sc{};
-  std::vector<void *> scene_allocs;
-  uint32_t n_instances = 0;
+  std::vector<void *> scene_allocs;     // geometry: nodes + triangles, normals
+  std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
+  uint32_t n_instances = 0, n_geometries = 0;
+  uint32_t tlas_capacity = 0;  // nodes reserved for the TLAS at the front of the node array
+  std::vector<uint32_t> geom_node_base, geom_tri_base, geom_root_start, geom_root_count;
 
   // state
   bool have_state = false;
@@ -178,11 +181,12 @@ bool walk_terminates(const MirtBVHNode *nodes, uint32_t n) {
 
 // Every index a kernel will follow is checked here, once, so that no launch
 // can read outside its buffers or walk forever.
-bool validate_scene(const MirtSceneDesc *d, std::string &why) {
+// The instance-dependent part: instances, transforms, materials, TLAS, lights,
+// per-material tables.
+bool validate_instances(const MirtSceneDesc *d, std::string &why) {
   auto bad = [&](const char *m) { why = m; return false; };
   if (!d->instances || !d->n_instances) return bad("no instances");
-  if (!d->geometry_offsets || !d->n_geometries || !d->vertices || !d->indices || !d->blas_nodes)
-    return bad("missing geometry buffers");
+  if (!d->n_geometries) return bad("missing geometry buffers");
   if (!d->materials || !d->n_materials || !d->transforms || !d->n_transforms) return bad("missing materials/transforms");
   if (!d->tlas_nodes || !d->n_tlas_nodes || !d->tlas_to_instances) return bad("missing TLAS buffers");
   if (d->n_tlas_nodes > kMaxNodesPerTree) return bad("TLAS has more than 2^24 nodes");
@@ -203,6 +207,34 @@ bool validate_scene(const MirtSceneDesc *d, std::string &why) {
     }
   }
   if (!walk_terminates(d->tlas_nodes, d->n_tlas_nodes)) return bad("TLAS links form a cycle");
+  const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
+  if (!no_lights)
+    for (uint32_t i = 0; i < d->n_light_sources; ++i)
+      if (d->light_sources[i] >= d->n_instances) return bad("light source instance out of range");
+  if (d->n_classic_refs) {
+    if (d->n_classic_refs != d->n_materials || !d->classic_refs) return bad("classic_refs must have one entry per material");
+    for (uint32_t i = 0; i < d->n_classic_refs; ++i) {
+      const MirtClassicMaterialRef r = d->classic_refs[i];
+      uint32_t lim = 0;
+      switch (r.kind) {
+        case MIRT_MAT_NONE: continue;
+        case MIRT_MAT_LAMBERTIAN: lim = d->lambertian ? d->n_lambertian : 0; break;
+        case MIRT_MAT_METALLIC: lim = d->metallic ? d->n_metallic : 0; break;
+        case MIRT_MAT_DIELECTRIC: lim = d->dielectric ? d->n_dielectric : 0; break;
+        case MIRT_MAT_EMISSIVE: lim = d->emissive ? d->n_emissive : 0; break;
+        default: return bad("unknown classic material kind");
+      }
+      if (r.data >= lim) return bad("classic material row out of range");
+    }
+  }
+  return true;
+}
+
+// The geometry part: per-geometry BLAS nodes, index rows, vertices.
+bool validate_geometry(const MirtSceneDesc *d, std::string &why) {
+  auto bad = [&](const char *m) { why = m; return false; };
+  if (!d->geometry_offsets || !d->n_geometries || !d->vertices || !d->indices || !d->blas_nodes)
+    return bad("missing geometry buffers");
   for (uint32_t g = 0; g < d->n_geometries; ++g) {
     const MirtGeometryOffsets &o = d->geometry_offsets[g];
     const bool last = g + 1 == d->n_geometries;
@@ -230,27 +262,11 @@ bool validate_scene(const MirtSceneDesc *d, std::string &why) {
       for (int k = 0; k < 3; ++k)
         if (d->indices[o.index + i].v[k] >= nv) return bad("vertex index out of range");
   }
-  const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
-  if (!no_lights)
-    for (uint32_t i = 0; i < d->n_light_sources; ++i)
-      if (d->light_sources[i] >= d->n_instances) return bad("light source instance out of range");
-  if (d->n_classic_refs) {
-    if (d->n_classic_refs != d->n_materials || !d->classic_refs) return bad("classic_refs must have one entry per material");
-    for (uint32_t i = 0; i < d->n_classic_refs; ++i) {
-      const MirtClassicMaterialRef r = d->classic_refs[i];
-      uint32_t lim = 0;
-      switch (r.kind) {
-        case MIRT_MAT_NONE: continue;
-        case MIRT_MAT_LAMBERTIAN: lim = d->lambertian ? d->n_lambertian : 0; break;
-        case MIRT_MAT_METALLIC: lim = d->metallic ? d->n_metallic : 0; break;
-        case MIRT_MAT_DIELECTRIC: lim = d->dielectric ? d->n_dielectric : 0; break;
-        case MIRT_MAT_EMISSIVE: lim = d->emissive ? d->n_emissive : 0; break;
-        default: return bad("unknown classic material kind");
-      }
-      if (r.data >= lim) return bad("classic material row out of range");
-    }
-  }
   return true;
+}
+
+bool validate_scene(const MirtSceneDesc *d, std::string &why) {
+  return validate_geometry(d, why) && validate_instances(d, why);
 }
 
 // Pack one tree's reference nodes into DNodes.  `sizes_out` receives the
@@ -448,6 +464,7 @@ int mirt_destroy(mirt_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_all(ctx->scene_allocs);
+  free_all(ctx->instance_allocs);
   free_all(ctx->state_allocs);
   for (EventPair &ep : ctx->ev_free) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   for (EventPair &ep : ctx->ev_pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -458,106 +475,104 @@ int mirt_destroy(mirt_ctx *ctx) {
   return MIRT_OK;
 }
 
-int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
-  ENTER(ctx);
-  if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
-  std::string why;
-  if (!validate_scene(d, why)) return fail(ctx, MIRT_ERR_BAD_SCENE, why);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  free_all(ctx->scene_allocs);
-  ctx->have_scene = false;
-  DScene sc{};
-
-  // The TLAS-leaf slot list; a leaf of kBigLeaf or more slots keeps its size
-  // out of line, indexed by its first slot.
-  std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
-  {
-    std::vector<uint32_t> t2i(d->tlas_to_instances, d->tlas_to_instances + d->n_tlas_to_instances);
-    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_to_inst, t2i);
-    if (rc != MIRT_OK) return rc;
-  }
-
-  // Nodes of every tree in one array, 64-B aligned: the TLAS block first, then
-  // one BLAS block per geometry.  Every block starts at an odd element, so the
-  // child pair (l, l+1), l odd, of a node shares a 64-B line.  Triangles per
-  // geometry.
-  std::vector<uint32_t> geom_node_base(d->n_geometries), geom_tri_base(d->n_geometries);
-  {
-    std::vector<DNode> nodes;
-    std::vector<DTri> tris(d->n_indices);
-    std::vector<DTriN> trins(d->n_indices);
-    nodes.reserve((size_t)d->n_tlas_nodes + d->n_blas_nodes + 2 * d->n_geometries + 3);
-    nodes.push_back(DNode{});  // element 0 unused: every block starts at an odd element
-    sc.tlas_base = (uint32_t)nodes.size();
-    nodes.resize(nodes.size() + d->n_tlas_nodes);
-    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, nodes.data() + sc.tlas_base, tlas_sizes.data());
-    {
-      std::vector<uint32_t> big(d->n_tlas_to_instances ? d->n_tlas_to_instances : 1u, 0u);
-      for (uint32_t i = 0; i < d->n_tlas_nodes; ++i) {
-        const DNode &dn = nodes[sc.tlas_base + i];
-        if ((dn.b >> 24) == kBigLeaf) big[dn.a] = tlas_sizes[i];
-      }
-      int rc = dev_upload(ctx, ctx->scene_allocs, &sc.tlas_big, big);
-      if (rc != MIRT_OK) return rc;
-    }
-    for (uint32_t g = 0; g < d->n_geometries; ++g) {
-      const MirtGeometryOffsets &o = d->geometry_offsets[g];
-      const bool last = g + 1 == d->n_geometries;
-      const uint32_t node_end = last ? d->n_blas_nodes : d->geometry_offsets[g + 1].blas_node;
-      const uint32_t idx_end = last ? d->n_indices : d->geometry_offsets[g + 1].index;
-      const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index;
-      if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
-      geom_node_base[g] = (uint32_t)nodes.size();
-      geom_tri_base[g] = o.index;
-      const size_t at = nodes.size();
-      nodes.resize(at + nn);
-      std::vector<uint32_t> sizes(nn);
-      pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data());
-      for (uint32_t p = 0; p < ni; ++p) {
-        const MirtIndex &f = d->indices[o.index + p];
-        const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
-        const MirtVertex &v1 = d->vertices[o.vertex + f.v[1]];
-        const MirtVertex &v2 = d->vertices[o.vertex + f.v[2]];
-        DTri t;
-        memset(&t, 0, sizeof(t));
-        t.p0x = v0.position[0]; t.p0y = v0.position[1]; t.p0z = v0.position[2];
-        t.e1x = v1.position[0] - v0.position[0]; t.e1y = v1.position[1] - v0.position[1]; t.e1z = v1.position[2] - v0.position[2];
-        t.e2x = v2.position[0] - v0.position[0]; t.e2y = v2.position[1] - v0.position[1]; t.e2z = v2.position[2] - v0.position[2];
-        tris[o.index + p] = t;
-        DTriN n;
-        memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
-        trins[o.index + p] = n;
-      }
-      // out-of-line leaf sizes ride in the first triangle of the leaf
-      for (uint32_t i = 0; i < nn; ++i) {
-        const DNode &dn = nodes[at + i];
-        if ((dn.b >> 24) == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
-      }
-    }
+// Geometry: the node array (a reserved TLAS block first, then one BLAS block
+// per geometry; every block starts at an odd element, so the child pair
+// (l, l+1), l odd, of a node shares a 64-B line) and the triangles, in one
+// allocation that the traversal kernels address through one buffer descriptor
+// with 32-bit byte offsets; the vertex normals beside it.
+static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
+  ctx->geom_node_base.assign(d->n_geometries, 0);
+  ctx->geom_tri_base.assign(d->n_geometries, 0);
+  ctx->geom_root_start.assign(d->n_geometries, 0);
+  ctx->geom_root_count.assign(d->n_geometries, 0);
+  std::vector<DNode> nodes;
+  std::vector<DTri> tris(d->n_indices);
+  std::vector<DTriN> trins(d->n_indices);
+  // room for the TLAS to grow without moving the BLAS blocks
+  ctx->tlas_capacity = d->n_tlas_nodes + d->n_tlas_nodes / 2u + 16u;
+  nodes.reserve((size_t)ctx->tlas_capacity + d->n_blas_nodes + 2 * d->n_geometries + 3);
+  nodes.push_back(DNode{});  // element 0 unused: every block starts at an odd element
+  sc.tlas_base = (uint32_t)nodes.size();
+  nodes.resize(nodes.size() + ctx->tlas_capacity);
+  for (uint32_t g = 0; g < d->n_geometries; ++g) {
+    const MirtGeometryOffsets &o = d->geometry_offsets[g];
+    const bool last = g + 1 == d->n_geometries;
+    const uint32_t node_end = last ? d->n_blas_nodes : d->geometry_offsets[g + 1].blas_node;
+    const uint32_t idx_end = last ? d->n_indices : d->geometry_offsets[g + 1].index;
+    const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index;
     if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
-    // Nodes and triangles share one allocation so that the traversal kernels
-    // address both through one buffer descriptor and 32-bit byte offsets.
-    const size_t node_bytes = nodes.size() * sizeof(DNode);
-    const size_t tri_off = (node_bytes + 255u) & ~(size_t)255u;
-    const size_t geo_bytes = tri_off + tris.size() * sizeof(DTri) + 64u;  // tail pad: 16-byte reads past the last record stay inside
-    if (geo_bytes >= ((size_t)1 << 32))
-      return fail(ctx, MIRT_ERR_BAD_SCENE, "nodes and triangles exceed the 4 GiB the traversal kernels address");
-    std::vector<unsigned char> geo(geo_bytes, 0);
-    memcpy(geo.data(), nodes.data(), node_bytes);
-    if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
-    const unsigned char *pg = nullptr;
-    int rc = dev_upload(ctx, ctx->scene_allocs, &pg, geo);
-    if (rc != MIRT_OK) return rc;
-    sc.geo = pg;
-    sc.geo_bytes = (uint32_t)geo_bytes;
-    sc.tri_off = (uint32_t)tri_off;
-    sc.nodes = reinterpret_cast<const DNode *>(pg);
-    sc.tri = reinterpret_cast<const DTri *>(pg + tri_off);
-    rc = dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
-    if (rc != MIRT_OK) return rc;
+    ctx->geom_node_base[g] = (uint32_t)nodes.size();
+    ctx->geom_tri_base[g] = o.index;
+    // light sampling draws from the primitive range of the BLAS root
+    // (archive/light.slang:60-64); for an inner root that is all triangles
+    const MirtBVHNode &root = d->blas_nodes[o.blas_node];
+    ctx->geom_root_start[g] = root.start;
+    ctx->geom_root_count[g] = root.end - root.start;
+    const size_t at = nodes.size();
+    nodes.resize(at + nn);
+    std::vector<uint32_t> sizes(nn);
+    pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data());
+    for (uint32_t p = 0; p < ni; ++p) {
+      const MirtIndex &f = d->indices[o.index + p];
+      const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
+      const MirtVertex &v1 = d->vertices[o.vertex + f.v[1]];
+      const MirtVertex &v2 = d->vertices[o.vertex + f.v[2]];
+      DTri t;
+      memset(&t, 0, sizeof(t));
+      t.p0x = v0.position[0]; t.p0y = v0.position[1]; t.p0z = v0.position[2];
+      t.e1x = v1.position[0] - v0.position[0]; t.e1y = v1.position[1] - v0.position[1]; t.e1z = v1.position[2] - v0.position[2];
+      t.e2x = v2.position[0] - v0.position[0]; t.e2y = v2.position[1] - v0.position[1]; t.e2z = v2.position[2] - v0.position[2];
+      tris[o.index + p] = t;
+      DTriN n;
+      memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
+      trins[o.index + p] = n;
+    }
+    // out-of-line leaf sizes ride in the first triangle of the leaf
+    for (uint32_t i = 0; i < nn; ++i) {
+      const DNode &dn = nodes[at + i];
+      if ((dn.b >> 24) == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
+    }
   }
+  if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
+  const size_t node_bytes = nodes.size() * sizeof(DNode);
+  const size_t tri_off = (node_bytes + 255u) & ~(size_t)255u;
+  const size_t geo_bytes = tri_off + tris.size() * sizeof(DTri) + 64u;  // tail pad: 16-byte reads past the last record stay inside
+  if (geo_bytes >= ((size_t)1 << 32))
+    return fail(ctx, MIRT_ERR_BAD_SCENE, "nodes and triangles exceed the 4 GiB the traversal kernels address");
+  std::vector<unsigned char> geo(geo_bytes, 0);
+  memcpy(geo.data(), nodes.data(), node_bytes);
+  if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
+  const unsigned char *pg = nullptr;
+  int rc = dev_upload(ctx, ctx->scene_allocs, &pg, geo);
+  if (rc != MIRT_OK) return rc;
+  sc.geo = pg;
+  sc.geo_bytes = (uint32_t)geo_bytes;
+  sc.tri_off = (uint32_t)tri_off;
+  sc.nodes = reinterpret_cast<const DNode *>(pg);
+  sc.tri = reinterpret_cast<const DTri *>(pg + tri_off);
+  return dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
+}
 
-  // instances
+// Everything that depends on instances, transforms or materials: the TLAS
+// block of the node array (written in place), the TLAS-leaf slot list, the
+// instance records with their matrices, materials, lights, per-material tables.
+static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
+  auto &own = ctx->instance_allocs;
+  int rc;
+  {
+    std::vector<DNode> tlas(d->n_tlas_nodes);
+    std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
+    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, tlas.data(), tlas_sizes.data());
+    HIP_TRY(ctx, hipMemcpy(const_cast<DNode *>(sc.nodes) + sc.tlas_base, tlas.data(), tlas.size() * sizeof(DNode),
+                           hipMemcpyHostToDevice));
+    // a leaf of kBigLeaf or more slots keeps its size out of line, indexed by its first slot
+    std::vector<uint32_t> big(d->n_tlas_to_instances ? d->n_tlas_to_instances : 1u, 0u);
+    for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
+      if ((tlas[i].b >> 24) == kBigLeaf) big[tlas[i].a] = tlas_sizes[i];
+    if ((rc = dev_upload(ctx, own, &sc.tlas_big, big)) != MIRT_OK) return rc;
+    std::vector<uint32_t> t2i(d->tlas_to_instances, d->tlas_to_instances + d->n_tlas_to_instances);
+    if ((rc = dev_upload(ctx, own, &sc.tlas_to_inst, t2i)) != MIRT_OK) return rc;
+  }
   {
     std::vector<DInst> insts(d->n_instances);
     for (uint32_t i = 0; i < d->n_instances; ++i) {
@@ -565,25 +580,19 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
       DInst di;
       memset(&di, 0, sizeof(di));
       instance_matrices(d->transforms[in.transform], di.m, di.mi);
-      di.node_base = geom_node_base[in.geometry];
-      di.tri_base = geom_tri_base[in.geometry];
+      di.node_base = ctx->geom_node_base[in.geometry];
+      di.tri_base = ctx->geom_tri_base[in.geometry];
       di.material = in.material;
       if (d->n_classic_refs) {
         di.kind = d->classic_refs[in.material].kind;
         di.kind_data = d->classic_refs[in.material].data;
       }
-      const MirtBVHNode &root = d->blas_nodes[d->geometry_offsets[in.geometry].blas_node];
-      // light sampling draws from the primitive range of the BLAS root
-      // (archive/light.slang:60-64); for an inner root that is all triangles
-      di.root_start = root.start;
-      di.root_count = root.end - root.start;
+      di.root_start = ctx->geom_root_start[in.geometry];
+      di.root_count = ctx->geom_root_count[in.geometry];
       insts[i] = di;
     }
-    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.inst, insts);
-    if (rc != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.inst, insts)) != MIRT_OK) return rc;
   }
-
-  // materials and per-material tables
   {
     std::vector<DMaterial> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -597,14 +606,12 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
       m.transmission = d->materials[i].transmission;
       mats[i] = m;
     }
-    int rc = dev_upload(ctx, ctx->scene_allocs, &sc.mat, mats);
-    if (rc != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.mat, mats)) != MIRT_OK) return rc;
     const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
     std::vector<uint32_t> lights;
     if (!no_lights) lights.assign(d->light_sources, d->light_sources + d->n_light_sources);
     sc.n_lights = (uint32_t)lights.size();
-    rc = dev_upload(ctx, ctx->scene_allocs, &sc.lights, lights);
-    if (rc != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.lights, lights)) != MIRT_OK) return rc;
     std::vector<float> lam, met, die, emi;
     if (d->n_classic_refs) {
       if (d->lambertian) lam.assign((const float *)d->lambertian, (const float *)d->lambertian + 4 * (size_t)d->n_lambertian);
@@ -612,12 +619,48 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
       if (d->dielectric) die.assign((const float *)d->dielectric, (const float *)d->dielectric + 8 * (size_t)d->n_dielectric);
       if (d->emissive) emi.assign((const float *)d->emissive, (const float *)d->emissive + 4 * (size_t)d->n_emissive);
     }
-    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.lambertian, lam)) != MIRT_OK) return rc;
-    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.metallic, met)) != MIRT_OK) return rc;
-    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.dielectric, die)) != MIRT_OK) return rc;
-    if ((rc = dev_upload(ctx, ctx->scene_allocs, &sc.emissive, emi)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.lambertian, lam)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.metallic, met)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.dielectric, die)) != MIRT_OK) return rc;
+    if ((rc = dev_upload(ctx, own, &sc.emissive, emi)) != MIRT_OK) return rc;
   }
+  return MIRT_OK;
+}
 
+int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
+  ENTER(ctx);
+  if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+  std::string why;
+  if (!validate_scene(d, why)) return fail(ctx, MIRT_ERR_BAD_SCENE, why);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->scene_allocs);
+  free_all(ctx->instance_allocs);
+  ctx->have_scene = false;
+  DScene sc{};
+  int rc = upload_geometry(ctx, d, sc);
+  if (rc == MIRT_OK) rc = upload_instances(ctx, d, sc);
+  if (rc != MIRT_OK) return rc;
+  ctx->sc = sc;
+  ctx->n_instances = d->n_instances;
+  ctx->n_geometries = d->n_geometries;
+  ctx->have_scene = true;
+  return MIRT_OK;
+}
+
+int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
+  ENTER(ctx);
+  if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  // a different set of geometries, or a TLAS that outgrew its block: start over
+  if (d->n_geometries != ctx->n_geometries || d->n_tlas_nodes > ctx->tlas_capacity) return mirt_scene_upload(ctx, d);
+  std::string why;
+  if (!validate_instances(d, why)) return fail(ctx, MIRT_ERR_BAD_SCENE, why);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  free_all(ctx->instance_allocs);
+  ctx->have_scene = false;
+  DScene sc = ctx->sc;
+  const int rc = upload_instances(ctx, d, sc);
+  if (rc != MIRT_OK) return rc;
   ctx->sc = sc;
   ctx->n_instances = d->n_instances;
   ctx->have_scene = true;

@@ -63,6 +63,11 @@ class Pathtracer:
         d = ffi.desc_from_arrays(arrays)
         self._check(self._L.mirt_scene_upload(self._h, C.byref(d)), "mirt_scene_upload")
 
+    def update_instances(self, arrays):
+        """Replace instances / transforms / materials / TLAS / lights; the geometry stays in HBM."""
+        d = ffi.desc_from_arrays(arrays)
+        self._check(self._L.mirt_scene_update_instances(self._h, C.byref(d)), "mirt_scene_update_instances")
+
     def create_state(self, width, height, threads, sources, params):
         sources = np.ascontiguousarray(sources, ffi.SampleSource)
         self._check(self._L.mirt_state_create(self._h, width, height, threads, sources.ctypes.data, len(sources),

@@ -383,3 +383,60 @@ def test_plain_c_driver_renders_the_same_sums(pt, config_scenes, tmp_path):
     assert int(words[1]) == want and int(words[3]) == int(cnt.sum()) == W * H * spp
     ppm = open(tmp_path / "c.ppm", "rb").read()
     assert ppm.startswith(b"P6\n96 64\n255\n") and len(ppm) == len(b"P6\n96 64\n255\n") + 3 * W * H
+
+
+def _three_suzannes(moved):
+    # the same two meshes, instances placed differently (and one more of them when `moved`)
+    s = host.Scene()
+    suz = s.load_model_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "suzanne.mirtmesh"))
+    rect = s.load_rect()
+    grey = s.add_material(host.make_material(colour=(0.7, 0.7, 0.7, 1.0)))
+    lamp = s.add_material(host.make_material(emissive=(12.0, 12.0, 12.0, 0.0)))
+    places = [((-1.2, 0.0, 3.0), (0.0, 0.3, 0.0)), ((1.2, 0.0, 3.5), (0.0, -0.4, 0.0)), ((0.0, 1.0, 4.5), (0.2, 0.0, 0.0))]
+    if moved:
+        places = [((-0.4, 0.3, 2.6), (0.5, 1.1, 0.0)), ((1.5, -0.5, 4.0), (0.0, 2.0, 0.3)), ((0.2, 0.8, 5.5), (0.0, 0.0, 1.0)),
+                  ((0.0, -1.0, 3.2), (1.0, 0.0, 0.0))]
+    for pos, rot in places:
+        s.spawn(host.make_transform(scale=(0.8, 0.8, 0.8), rotation=rot, translation=pos), grey, suz)
+    s.spawn(host.make_transform(scale=(2.0, 2.0, 1.0), rotation=(1.5707964, 0.0, 0.0), translation=(0.0, 2.5, 3.5)), lamp, rect)
+    arrays = s.bind()
+    s.close()
+    return arrays
+
+
+def test_instance_update_keeps_geometry_and_matches_a_fresh_upload(pt):
+    # mirt_scene_update_instances: transforms / instance count / TLAS change, the
+    # BLAS nodes and triangles stay in HBM; results equal a fresh upload and the oracle
+    a, b = _three_suzannes(False), _three_suzannes(True)
+    for k in ("geometry_offsets", "vertices", "indices", "blas_nodes"):
+        assert np.array_equal(a[k], b[k])
+    assert len(b["instances"]) == len(a["instances"]) + 1
+    rays = random_rays(50021, 5, centre=(0.0, 0.0, 3.5), spread=2.5)
+    pt.upload_scene(a)
+    assert hits_equal(pt.trace_closest(rays), po.Scene(a).trace_closest(rays))
+    pt.update_instances(b)
+    sc = po.Scene(b)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want) and gc.as_dict() == wc.as_dict()
+    fresh = pathtracer.Pathtracer(0)
+    fresh.upload_scene(b)
+    assert hits_equal(fresh.trace_closest(rays), want)
+    fresh.close()
+    # and a render on the updated scene
+    W, H = 64, 48
+    src = host.make_sample_sources(W, H, 9)
+    cam = host.default_camera(W, H)
+    pt.create_state(W, H, 2000, src, pathtracer.default_params(max_bounces=5, seed=9))
+    pt.set_camera(cam)
+    pt.render_spp(2)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=5, seed=9), 0, 2)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+    # back again, then a broken update is refused and leaves an error, not a crash
+    pt.update_instances(a)
+    assert hits_equal(pt.trace_closest(rays), po.Scene(a).trace_closest(rays))
+    bad = {k: v.copy() for k, v in b.items()}
+    bad["tlas_to_instances"][0] = 99
+    with pytest.raises(pathtracer.MirtError, match="tlas_to_instances"):
+        pt.update_instances(bad)
