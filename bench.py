@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json's metric configuration, "dragon.obj 1080p, 8 bounces"):
+Workload (the headline metric's configuration, "dragon.obj 1080p, 8 bounces"):
 the reference's simple_scene — open Cornell box + dragon — at 1920x1080 with
 the reference's shuffled sample-source order, 8 bounces, sky 10.  dragon.obj is
 absent from the reference checkout; unless tests/golden/dragon.{obj,mirtmesh}
