@@ -440,3 +440,32 @@ def test_instance_update_keeps_geometry_and_matches_a_fresh_upload(pt):
     bad["tlas_to_instances"][0] = 99
     with pytest.raises(pathtracer.MirtError, match="tlas_to_instances"):
         pt.update_instances(bad)
+
+
+def test_degenerate_trees_single_instance_single_leaf(pt):
+    # one rect: the TLAS root is a leaf and so is the BLAS root (every walk wraps at once)
+    s = host.Scene()
+    rect = s.load_rect()
+    m = s.add_material(host.make_material(emissive=(3.0, 3.0, 3.0, 0.0)))
+    s.spawn(host.make_transform(scale=(2.0, 2.0, 1.0), translation=(0.0, 0.0, 3.0)), m, rect)
+    arrays = s.bind()
+    s.close()
+    assert len(arrays["tlas_nodes"]) == 1 and arrays["tlas_nodes"]["is_leaf"][0] == 1
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    rays = random_rays(20011, 8, centre=(0.0, 0.0, 3.0), spread=1.5)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want) and gc.as_dict() == wc.as_dict()
+    assert 100 < (want["instance_id"] != ffi.NO_HIT).sum() < len(rays)
+    tmax = np.full(len(rays), 2.5, "<f4")
+    assert hits_equal(pt.trace_any(rays, tmax), sc.trace_any(rays, tmax))
+    W, H = 48, 32
+    src = host.make_sample_sources(W, H, 4)
+    cam = host.default_camera(W, H)
+    pt.create_state(W, H, 300, src, pathtracer.default_params(max_bounces=3, seed=4))
+    pt.set_camera(cam)
+    pt.render_spp(2)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=3, seed=4), 0, 2)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
