@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B on one box: tools/ab_bench.sh <libA.so> <libB.so> ... -> extend ms per launch and Mrays/s for each, twice.
+mkdir -p gpurun_out
+for round in 1 2; do
+  for lib in "$@"; do
+    MIRT_DEVICE_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3 > gpurun_out/ab_$lib.json 2>gpurun_out/ab_$lib.err || exit 1
+    python3 -c "
+import json,sys; d=json.load(open('gpurun_out/ab_$lib.json')); print('$lib', round(d['value'],1), 'Mrays/s  extend', round(d['roofline']['launch_ms'],3), 'ms')"
+  done
+done
