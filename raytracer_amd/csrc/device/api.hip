@@ -271,7 +271,9 @@ bool validate_scene(const MirtSceneDesc *d, std::string &why) {
 
 // Pack one tree's reference nodes into DNodes.  `sizes_out` receives the
 // out-of-line size of every node (only read for leaves marked kBigLeaf).
-void pack_nodes(const MirtBVHNode *src, uint32_t n, DNode *dst, uint32_t *sizes_out) {
+// TLAS leaves are all marked kBigLeaf (`all_big`): the walk hands every leaf
+// so marked to its service point, which is where instances are entered.
+void pack_nodes(const MirtBVHNode *src, uint32_t n, DNode *dst, uint32_t *sizes_out, bool all_big) {
   for (uint32_t i = 0; i < n; ++i) {
     const MirtBVHNode &s = src[i];
     DNode d;
@@ -281,7 +283,7 @@ void pack_nodes(const MirtBVHNode *src, uint32_t n, DNode *dst, uint32_t *sizes_
     // test; any other value walks on as an inner node.
     if (s.is_leaf == 1) {
       const uint32_t cnt = s.end - s.start;  // >= 1, checked by validate_scene
-      const uint32_t tag = cnt < kBigLeaf ? cnt : kBigLeaf;
+      const uint32_t tag = (cnt < kBigLeaf && !all_big) ? cnt : kBigLeaf;
       d.a = s.start;
       d.b = (s.right & kSkipMask) | (tag << 24);
       if (sizes_out) sizes_out[i] = cnt;
@@ -511,7 +513,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     const size_t at = nodes.size();
     nodes.resize(at + nn);
     std::vector<uint32_t> sizes(nn);
-    pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data());
+    pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data(), false);
     for (uint32_t p = 0; p < ni; ++p) {
       const MirtIndex &f = d->indices[o.index + p];
       const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
@@ -562,7 +564,7 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   {
     std::vector<DNode> tlas(d->n_tlas_nodes);
     std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
-    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, tlas.data(), tlas_sizes.data());
+    pack_nodes(d->tlas_nodes, d->n_tlas_nodes, tlas.data(), tlas_sizes.data(), true);
     HIP_TRY(ctx, hipMemcpy(const_cast<DNode *>(sc.nodes) + sc.tlas_base, tlas.data(), tlas.size() * sizeof(DNode),
                            hipMemcpyHostToDevice));
     // a leaf of kBigLeaf or more slots keeps its size out of line, indexed by its first slot

@@ -62,35 +62,48 @@ __device__ __forceinline__ uint32_t trv_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// min / max that return the non-NaN operand, as single instructions.  The
+// compiler's fminf / fmaxf first quiet a possible signalling NaN with an extra
+// v_max per operand; no signalling NaN can reach these (their operands are
+// arithmetic results, the seed, and a t that is FLT_MAX, a client tmax checked
+// on the host or an accepted t2), so the bare instructions give the same bits.
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float hw_min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // rayBoxIntersect (shaders/ray_extend.slang:94-111) with 1/dir hoisted out
-// of the walk.  tmin starts at the lowest finite float (float.minValue).
-__device__ __forceinline__ bool ray_box(v3 pos, v3 dinv, const float4 lo, const float4 hi, float tmax_in,
-                                        float &tmin_out, float &tmax_out) {
-  float tmin = -FLT_MAX;
-  float tmax = tmax_in;
-  {
-    const bool s = dinv.x >= 0.0f;
-    const float bmin = s ? lo.x : hi.x, bmax = s ? hi.x : lo.x;
-    const float dmin = (bmin - pos.x) * dinv.x, dmax = (bmax - pos.x) * dinv.x;
-    tmin = fmax_nn(dmin, tmin);
-    tmax = fmin_nn(dmax, tmax);
-  }
-  {
-    const bool s = dinv.y >= 0.0f;
-    const float bmin = s ? lo.y : hi.y, bmax = s ? hi.y : lo.y;
-    const float dmin = (bmin - pos.y) * dinv.y, dmax = (bmax - pos.y) * dinv.y;
-    tmin = fmax_nn(dmin, tmin);
-    tmax = fmin_nn(dmax, tmax);
-  }
-  {
-    const bool s = dinv.z >= 0.0f;
-    const float bmin = s ? lo.z : hi.z, bmax = s ? hi.z : lo.z;
-    const float dmin = (bmin - pos.z) * dinv.z, dmax = (bmax - pos.z) * dinv.z;
-    tmin = fmax_nn(dmin, tmin);
-    tmax = fmin_nn(dmax, tmax);
-  }
-  tmin_out = tmin;
-  tmax_out = tmax;
+// of the walk.  The shader starts tmin at the lowest finite float
+// (float.minValue) and tlasFirstHit additionally rejects a box with
+// tmax < 0 and tmin < 0 (ray_extend.slang:177).  Both are one comparison
+// here: with tmin seeded with `tmin_seed` = 0 instead of -FLT_MAX,
+//   max(tmin, 0) <= tmax  <=>  tmin <= tmax and 0 <= tmax
+// and tmin <= tmax makes (tmax >= 0 or tmin >= 0) the same as tmax >= 0.
+// The walk passes 0 in the TLAS and -FLT_MAX in a BLAS.
+__device__ __forceinline__ bool ray_box(v3 pos, v3 dinv, const float4 lo, const float4 hi, float tmin_seed,
+                                        float tmax_in) {
+  const bool sx = dinv.x >= 0.0f, sy = dinv.y >= 0.0f, sz = dinv.z >= 0.0f;
+  const float dminx = ((sx ? lo.x : hi.x) - pos.x) * dinv.x, dmaxx = ((sx ? hi.x : lo.x) - pos.x) * dinv.x;
+  const float dminy = ((sy ? lo.y : hi.y) - pos.y) * dinv.y, dmaxy = ((sy ? hi.y : lo.y) - pos.y) * dinv.y;
+  const float dminz = ((sz ? lo.z : hi.z) - pos.z) * dinv.z, dmaxz = ((sz ? hi.z : lo.z) - pos.z) * dinv.z;
+  const float tmin = hw_max3(dminz, dminy, hw_max(dminx, tmin_seed));
+  const float tmax = hw_min3(dmaxz, dmaxy, hw_min(dmaxx, tmax_in));
   return tmin <= tmax;
 }
 
@@ -239,6 +252,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   uint32_t cur = 0;                 // node under the cursor (index within its tree)
   uint32_t nbase = 0, tbase = 0;    // byte offsets of the tree's node 0 and of the instance's triangle 0
   uint32_t excl_prim = kNoExclude;  // the triangle of this instance the ray must not hit, if any
+  float tseed = 0.0f;               // what ray_box seeds tmin with: 0 in the TLAS, -FLT_MAX in a BLAS
   // the ray in the space of the tree being walked (world for the TLAS)
   v3 cpos = V3(0.0f, 0.0f, 0.0f), cdir = V3(1.0f, 1.0f, 1.0f), cdinv = V3(1.0f, 1.0f, 1.0f);
   // what is left of the leaf the lane is on: count == 0 means none (BLAS: triangles, TLAS: slots)
@@ -359,6 +373,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
               slot_i = s_tlas[1][tid];
               slot_end = s_tlas[2][tid];
               nbase = tlas_nbase;
+              tseed = 0.0f;
             } else {
               if ((fl & F_WRAP) != 0u) fl |= F_TDONE;
               if (leaf_count != 0u) {
@@ -390,6 +405,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
               cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
               excl_prim = id == s_tag[0][tid] ? s_tag[1][tid] : kNoExclude;
               cur = 0u;
+              tseed = -FLT_MAX;
               fl = (fl | F_BLAS) & ~(F_WRAP | F_HOLD);
             } else if ((fl & F_TDONE) != 0u) {
               fl &= ~F_WALK;
@@ -447,6 +463,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             s_tag[2][tid] = ray.payload;
             cur = 0u;
             nbase = tlas_nbase;
+            tseed = 0.0f;
             leaf_count = 0u;
           }
           const uint32_t taken = (uint32_t)__popcll(need);
@@ -475,14 +492,11 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         float4 a2 = a1;
         if (is_tri) a2 = geo_load16(geo, off + 32u);  // issued with the other two, before either test
         if (!is_tri) {
-          const bool in_blas = (fl & F_BLAS) != 0u;
           if (COUNT) {
-            if (in_blas) lc.blas_nodes++;
+            if ((fl & F_BLAS) != 0u) lc.blas_nodes++;
             else lc.tlas_nodes++;
           }
-          float t0, t1;
-          bool hit = ray_box(cpos, cdinv, a0, a1, t, t0, t1);
-          hit = hit && (in_blas || t1 >= 0.0f || t0 >= 0.0f);  // the TLAS also rejects boxes behind the ray
+          const bool hit = ray_box(cpos, cdinv, a0, a1, tseed, t);
           const uint32_t wa = __float_as_uint(a0.w), wb = __float_as_uint(a1.w);
           const uint32_t leaf = wb >> 24;
           const bool leaf_hit = hit && leaf != 0u;
@@ -490,8 +504,9 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
           leaf_start = wa;
           leaf_count = leaf_hit ? leaf : 0u;  // kBigLeaf is resolved by whoever takes the leaf
           const bool wrapped = cur == 0u;
-          // small BLAS leaves are scanned by the lane itself; everything else waits for the service point
-          const bool holdc = leaf_hit ? (!in_blas || leaf >= kCoopLeaf) : wrapped;
+          // small leaves are scanned by the lane itself; big ones and every TLAS leaf (all
+          // tagged kBigLeaf) wait for the service point
+          const bool holdc = leaf_hit ? leaf >= kCoopLeaf : wrapped;
           fl = (fl & ~(F_WRAP | F_HOLD)) | (wrapped ? F_WRAP : 0u) | (holdc ? F_HOLD : 0u);
         } else {
           const uint32_t p = leaf_start;
