@@ -96,10 +96,14 @@ def main():
         args.gpus = world
     dist = None
     import torch
-    if world > 1:
+    # MIRT_BENCH_DIST=1 takes the collective path with a single rank too (a rehearsal
+    # of the multi-GPU code on a one-GPU box)
+    if world > 1 or os.environ.get("MIRT_BENCH_DIST") == "1":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
     from raytracer_amd import distributed, host, pathtracer

@@ -469,3 +469,28 @@ def test_degenerate_trees_single_instance_single_leaf(pt):
     s4, cnt = pt.read_accum()
     w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=3, seed=4), 0, 2)
     assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+
+
+@pytest.mark.gpu
+def test_bench_collective_path_with_one_rank():
+    """bench.py's multi-GPU branch (RCCL process group, device-to-device accumulator
+    all-reduce, MAX / SUM of the per-rank figures) rehearsed with a single rank."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIRT_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--config", "1", "--spp-per-step", "4", "--paths-per-pixel", "2", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["rays"] > 0
+    assert d["reduce_ms"] > 0.0  # the collective ran
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
+    assert d["config"]["parallelism"] == "spp split x1"
