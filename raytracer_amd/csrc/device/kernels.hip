@@ -399,7 +399,10 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &
 // extensionMain's epilogue and shadeMain in one pass over the extension queue
 // (uber shading): the hit record stays in registers between the two, a miss
 // adds the sky and ends the path.
-__global__ __launch_bounds__(kStreamBlock) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
+#ifndef MIRT_SHADE_WAVES
+#define MIRT_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
@@ -536,7 +539,10 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
   hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, st, fp);
 }
 
-constexpr int kEngineBlocksPerCU = 5;
+#ifndef MIRT_ENGINE_BLOCKS
+#define MIRT_ENGINE_BLOCKS 5
+#endif
+constexpr int kEngineBlocksPerCU = MIRT_ENGINE_BLOCKS;
 
 int trace_grid_blocks(int num_cus) {
   static int per_cu = 0;
