@@ -490,6 +490,12 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   std::vector<DNode> nodes;
   std::vector<DTri> tris(d->n_indices);
   std::vector<DTriN> trins(d->n_indices);
+  struct ScanLeaf {
+    uint32_t first_tri, count;
+    size_t block;
+  };
+  std::vector<ScanLeaf> scan_leaves;
+  size_t scan_blocks = 0;
   // room for the TLAS to grow without moving the BLAS blocks
   ctx->tlas_capacity = d->n_tlas_nodes + d->n_tlas_nodes / 2u + 16u;
   nodes.reserve((size_t)ctx->tlas_capacity + d->n_blas_nodes + 2 * d->n_geometries + 3);
@@ -529,19 +535,44 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
       trins[o.index + p] = n;
     }
-    // out-of-line leaf sizes ride in the first triangle of the leaf
+    // out-of-line leaf sizes ride in the first triangle of the leaf; leaves the
+    // whole wave scans get a second, lane-interleaved copy of their triangles
     for (uint32_t i = 0; i < nn; ++i) {
       const DNode &dn = nodes[at + i];
-      if ((dn.b >> 24) == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
+      const uint32_t tag = dn.b >> 24;
+      if (tag == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
+      if (tag >= kScanLeafMin) {
+        const uint32_t cnt = tag == kBigLeaf ? sizes[i] : tag;
+        scan_leaves.push_back(ScanLeaf{o.index + dn.a, cnt, scan_blocks});
+        scan_blocks += (cnt + 63u) / 64u;
+      }
     }
   }
   if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
   const size_t node_bytes = nodes.size() * sizeof(DNode);
   const size_t tri_off = (node_bytes + 255u) & ~(size_t)255u;
-  const size_t geo_bytes = tri_off + tris.size() * sizeof(DTri) + 64u;  // tail pad: 16-byte reads past the last record stay inside
+  const size_t scan_off = (tri_off + tris.size() * sizeof(DTri) + 64u + 255u) & ~(size_t)255u;
+  const size_t geo_bytes = scan_off + scan_blocks * (size_t)kScanBlockBytes + 64u;  // tail pad: 16-byte reads past the last record stay inside
   if (geo_bytes >= ((size_t)1 << 32))
     return fail(ctx, MIRT_ERR_BAD_SCENE, "nodes and triangles exceed the 4 GiB the traversal kernels address");
   std::vector<unsigned char> geo(geo_bytes, 0);
+  // Scan blocks: 64 triangles each, as three planes a wave reads with one
+  // contiguous load each — plane 0 (p0.xyz, e1.x) and plane 1 (e1.yz, e2.xy)
+  // 16 bytes per lane, plane 2 (e2.z) 4 bytes per lane.  The byte offset of a
+  // leaf's first block rides in the first triangle of the leaf.
+  for (const ScanLeaf &sl : scan_leaves) {
+    const size_t first = scan_off + sl.block * (size_t)kScanBlockBytes;
+    tris[sl.first_tri].e1w = (uint32_t)first;
+    for (uint32_t k = 0; k < sl.count; ++k) {
+      const DTri &t = tris[sl.first_tri + k];
+      unsigned char *blk = geo.data() + first + (k / 64u) * (size_t)kScanBlockBytes;
+      const uint32_t lane = k % 64u;
+      const float plane0[4] = {t.p0x, t.p0y, t.p0z, t.e1x}, plane1[4] = {t.e1y, t.e1z, t.e2x, t.e2y};
+      memcpy(blk + lane * 16u, plane0, 16);
+      memcpy(blk + 1024u + lane * 16u, plane1, 16);
+      memcpy(blk + 2048u + lane * 4u, &t.e2z, 4);
+    }
+  }
   memcpy(geo.data(), nodes.data(), node_bytes);
   if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
   const unsigned char *pg = nullptr;

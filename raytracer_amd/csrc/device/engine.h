@@ -32,9 +32,7 @@
 
 namespace mirt {
 
-#ifndef MIRT_COOP_LEAF
-#define MIRT_COOP_LEAF 24u
-#endif
+#define MIRT_COOP_LEAF kScanLeafMin
 #ifndef MIRT_REFILL_BELOW
 #define MIRT_REFILL_BELOW 40
 #endif
@@ -44,7 +42,7 @@ constexpr int kRefillBelow = MIRT_REFILL_BELOW;  // refill when fewer lanes than
 #define MIRT_SERVICE_FRAC 4
 #endif
 constexpr int kServiceFrac = MIRT_SERVICE_FRAC;  // service point when 1/kServiceFrac of the walking lanes are held
-static_assert(MIRT_COOP_LEAF <= 255u, "leaves of kBigLeaf triangles or more must go to the whole-wave phase");
+static_assert(kScanLeafMin <= 255u, "leaves of kBigLeaf triangles or more must go to the whole-wave phase");
 
 struct LaneCounts {
   uint32_t tlas_nodes = 0, instance_visits = 0, blas_nodes = 0, triangles = 0;
@@ -154,6 +152,7 @@ struct WorkSource {
     ph_acc[k] += ph_now - ph_t0;                               \
     ph_t0 = ph_now;                                            \
   } while (0)
+#define MIRT_PH_RESET (ph_t0 = __builtin_amdgcn_s_memtime())
 #define MIRT_PH_COUNT(k) (ph_acc[k] += 1ull)
 #define MIRT_PH_ADD(k, n) (ph_acc[k] += (unsigned long long)(n))
 #define MIRT_PH_FLUSH(ptr)                                                        \
@@ -165,6 +164,7 @@ struct WorkSource {
 #else
 #define MIRT_PH_DECL
 #define MIRT_PH_MARK(k)
+#define MIRT_PH_RESET
 #define MIRT_PH_COUNT(k)
 #define MIRT_PH_ADD(k, n)
 #define MIRT_PH_FLUSH(ptr)
@@ -281,14 +281,15 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         unsigned long long bigmask =
             __ballot((fl & (F_WALK | F_HOLD | F_BLAS)) == (F_WALK | F_HOLD | F_BLAS) && leaf_count != 0u);
         const bool any_big = bigmask != 0ull;
+        MIRT_PH_RESET;
         while (bigmask != 0ull) {
           const int owner = __ffsll((long long)bigmask) - 1;
           bigmask &= bigmask - 1ull;
           MIRT_PH_COUNT(3);
-          // the owner's ray and leaf, wave-uniform (scalar registers)
-          auto bcast_f = [&](float x) {
-            return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), owner));
-          };
+          // the owner's ray and leaf, wave-uniform
+          // (the ray through a lane shuffle, so that it stays in vector registers: an
+          // operand read from a scalar register slows every instruction of the scan down)
+          auto bcast_f = [&](float x) { return __shfl(x, owner); };
           auto bcast_u = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, owner); };
           const v3 op = V3(bcast_f(cpos.x), bcast_f(cpos.y), bcast_f(cpos.z));
           const v3 od = V3(bcast_f(cdir.x), bcast_f(cdir.y), bcast_f(cdir.z));
@@ -297,19 +298,21 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
           const uint32_t otbase = bcast_u(tbase);
           uint32_t ocount = bcast_u(leaf_count);
           if (ocount == kBigLeaf) ocount = geo_load4(geo, otbase + ostart * 48u + 12u);  // size stored out of line
+          const uint32_t oblocks = geo_load4(geo, otbase + ostart * 48u + 28u);  // the leaf's scan blocks
           const uint32_t oskip = bcast_u(excl_prim);
           // per-lane best over triangles ostart + lane, + 64, ...
           // key: ANY -> index (first accepted in index order);
           //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
           unsigned long long key = ~0ull;
           float ku = 0.0f, kv = 0.0f, kt = 0.0f;
-          for (uint32_t k = lane; k < ocount; k += 64u) {
+          uint32_t boff = oblocks + lane * 16u;
+          for (uint32_t k = lane; k < ocount; k += 64u, boff += kScanBlockBytes) {
             const uint32_t p = ostart + k;
             if (p == oskip) continue;
-            const uint32_t off = otbase + p * 48u;
-            const float4 a0 = geo_load16(geo, off), a1 = geo_load16(geo, off + 16u), a2 = geo_load16(geo, off + 32u);
+            const float4 a0 = geo_load16(geo, boff), a1 = geo_load16(geo, boff + 1024u);
+            const float a2 = __uint_as_float(geo_load4(geo, boff + 2048u - lane * 12u));
             float t2, u, v;
-            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a0.w, a1.x, a1.y), V3(a1.z, a1.w, a2), t2, u, v) &&
                 !(t2 > ot || t2 < 0.0f)) {
               const unsigned long long kk =
                   ANY ? (unsigned long long)p
@@ -352,6 +355,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         // 1/dir is not needed by the scan: rebuilding it here (same operation, same
         // bits) instead of keeping it frees its registers for the scan
         if (any_big) cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+        MIRT_PH_MARK(7);
       }
 
       // ---------------------------------------------------- housekeeping

@@ -14,6 +14,8 @@
 //                  per test instead of a 16-B index row plus three 48-B
 //                  vertices.  e1/e2 are the same f32 subtractions the kernel
 //                  would do, so results are unchanged.
+//   scan blocks    a lane-interleaved second copy of the triangles of big leaves
+//                  (see kScanLeafMin below).
 //   DTriN (48 B)   the three vertex normals, fetched once for the winning
 //                  triangle only.
 //   DInst (128 B)  world->object and object->world 3x4 matrices (the
@@ -50,9 +52,17 @@ constexpr uint32_t kBigLeaf = 255u;
 struct DTri {
   float p0x, p0y, p0z;
   uint32_t p0w;  // out-of-line leaf size for the first triangle of a big leaf
-  float e1x, e1y, e1z, e1w;
+  float e1x, e1y, e1z;
+  uint32_t e1w;  // first triangle of a leaf the whole wave scans: byte offset of its scan blocks
   float e2x, e2y, e2z, e2w;
 };
+
+// Leaves with kScanLeafMin or more triangles are tested by a whole wave, 64
+// triangles per step.  They keep a second copy of their triangles in blocks of
+// 64, each block three lane-interleaved planes (16 + 16 + 4 bytes per lane), so
+// that a step is three contiguous loads instead of three loads of stride 48.
+constexpr uint32_t kScanLeafMin = 24u;
+constexpr uint32_t kScanBlockBytes = 2304u;
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
 
 struct DTriN {

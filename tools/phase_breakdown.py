@@ -20,3 +20,4 @@ if ph[5]:
     print(f"  iterations {its:.3e} ({its/rw:.1f} per 64 rays), service points {ph[0]:.3e} ({ph[0]/rw:.1f} per 64 rays), whole-wave leaves {ph[3]:.3e}")
     print(f"  lanes per iteration: walking {ph[6]/its:.1f}, node steps {ph[1]/its:.1f}, triangle steps {ph[2]/its:.1f}")
     print(f"  per ray: node steps {ph[1]/st.extend_rays:.1f}, lane triangle steps {ph[2]/st.extend_rays:.1f}")
+    print(f"  wave time in whole-wave leaf scans: {100.0 * ph[7] / ph[4]:.1f} % ({ph[7] / max(ph[3], 1):.0f} cycles per scan; wave cycles counted at 100 MHz)")
