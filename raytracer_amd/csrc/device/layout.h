@@ -61,7 +61,10 @@ struct DTri {
 // triangles per step.  They keep a second copy of their triangles in blocks of
 // 64, each block three lane-interleaved planes (16 + 16 + 4 bytes per lane), so
 // that a step is three contiguous loads instead of three loads of stride 48.
-constexpr uint32_t kScanLeafMin = 24u;
+#ifndef MIRT_SCAN_LEAF_MIN
+#define MIRT_SCAN_LEAF_MIN 24u
+#endif
+constexpr uint32_t kScanLeafMin = MIRT_SCAN_LEAF_MIN;
 constexpr uint32_t kScanBlockBytes = 2304u;
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
 
