@@ -36,9 +36,9 @@ def config_scenes():
 
 @pytest.fixture(scope="session")
 def small_knot_scene():
-    """A Cornell box around a small procedural knot: has leaves far larger than the
-    builder's threshold (the one-sided-partition bail-out), so it exercises the
-    wave-cooperative leaf path."""
+    """A Cornell box around a small procedural knot: has leaves larger than the
+    builder's threshold of four (the one-sided-partition bail-out, up to ten
+    triangles here) next to ordinary ones."""
     s = host.Scene()
     mesh = s.load_knot(96, 24, 7)
     mat = s.add_material(host.make_material(colour=(1.0, 1.0, 1.0, 1.0), metallic=0.2, roughness=0.1))

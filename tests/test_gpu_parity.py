@@ -494,3 +494,89 @@ def test_bench_collective_path_with_one_rank():
     assert d["reduce_ms"] > 0.0  # the collective ran
     assert d["roofline"]["achieved"] > 0 and d["roofline"]["launches"] > 0
     assert d["config"]["parallelism"] == "spp split x1"
+
+
+def _comb_scene(leaf_sizes, seed):
+    """One instance of a triangle soup under a hand-built comb BVH whose leaves have the
+    given sizes: root -> (leaf 0, inner) -> (leaf 1, inner) ... -> (leaf k-2, leaf k-1)."""
+    s = host.Scene()
+    rect = s.load_rect()
+    m = s.add_material(host.make_material(colour=(0.7, 0.7, 0.7, 1.0)))
+    s.spawn(host.make_transform(), m, rect)
+    arrays = dict(s.bind())
+    s.close()
+    rng = np.random.default_rng(seed)
+    n = int(sum(leaf_sizes))
+    c = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.0, 4.0, n)], 1)
+    corners = c[:, None, :] + rng.uniform(-0.25, 0.25, (n, 3, 3))
+    verts = np.zeros(3 * n, arrays["vertices"].dtype)
+    verts["position"][:, :3] = corners.reshape(-1, 3).astype("<f4")
+    verts["position"][:, 3] = 1.0
+    verts["normal"][:, 2] = -1.0
+    idx = np.zeros(n, arrays["indices"].dtype)
+    idx["v"][:, :3] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    k = len(leaf_sizes)
+    nodes = np.zeros(2 * k - 1, arrays["blas_nodes"].dtype)
+    starts = np.concatenate([[0], np.cumsum(leaf_sizes)]).astype(np.uint32)
+    pos = verts["position"][:, :3].reshape(n, 3, 3)
+
+    def leaf(at, i, skip):
+        nodes[at]["is_leaf"] = 1
+        nodes[at]["start"], nodes[at]["end"] = starts[i], starts[i + 1]
+        nodes[at]["right"] = skip
+        p = pos[starts[i]:starts[i + 1]].reshape(-1, 3)
+        nodes[at]["lb"][:3], nodes[at]["ub"][:3] = p.min(0), p.max(0)
+
+    nodes[0]["left"], nodes[0]["right"] = 1, 0
+    for i in range(k - 1):
+        last = i == k - 2
+        leaf(2 * i + 1, i, 2 * i + 2)
+        if last:
+            leaf(2 * i + 2, i + 1, 0)
+        else:
+            nodes[2 * i + 2]["left"], nodes[2 * i + 2]["right"] = 2 * i + 3, 0
+    for at in range(2 * k - 2, -1, -1):  # inner boxes, children first
+        if nodes[at]["is_leaf"] != 1:
+            l = int(nodes[at]["left"])
+            nodes[at]["lb"][:3] = np.minimum(nodes[l]["lb"][:3], nodes[l + 1]["lb"][:3])
+            nodes[at]["ub"][:3] = np.maximum(nodes[l]["ub"][:3], nodes[l + 1]["ub"][:3])
+            nodes[at]["start"], nodes[at]["end"] = nodes[l]["start"], nodes[l + 1]["end"]
+    arrays["vertices"], arrays["indices"], arrays["blas_nodes"] = verts, idx, nodes
+    tl = arrays["tlas_nodes"].copy()
+    tl["lb"][0][:3], tl["ub"][0][:3] = nodes[0]["lb"][:3], nodes[0]["ub"][:3]
+    arrays["tlas_nodes"] = tl
+    return arrays
+
+
+def test_whole_wave_leaves_of_every_block_shape(pt):
+    """Leaves around every boundary of the whole-wave scan: its threshold (23 / 24), one
+    64-triangle block and its neighbours (63 / 64 / 65), several blocks, a ragged tail, and
+    the sizes whose count is stored out of line (254 / 255 / 256), mixed with small leaves."""
+    sizes = [24, 63, 1, 64, 65, 4, 128, 23, 254, 255, 256, 300, 2, 777]
+    arrays = _comb_scene(sizes, 12)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    rays = random_rays(30011, 13, centre=(0.0, 0.0, 3.0), spread=2.0)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want) and gc.as_dict() == wc.as_dict()
+    hit = want["instance_id"] != ffi.NO_HIT
+    assert 3000 < hit.sum() < len(rays)
+    # every scanned leaf is somebody's closest hit, so every block shape has produced a winner
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    leaf_of = np.searchsorted(starts, want["triangle_id"][hit], side="right") - 1
+    assert set(leaf_of.tolist()) >= {i for i, n in enumerate(sizes) if n >= 23}
+    tmax = np.full(len(rays), 2.0, "<f4")
+    want_any, wca = sc.trace_any(rays, tmax, True)
+    got_any, gca = pt.trace_any(rays, tmax, True)
+    assert hits_equal(got_any, want_any) and gca.as_dict() == wca.as_dict()
+    # bounce rays leave from triangles inside those leaves: the excluded triangle sits in a scanned block
+    W, H = 64, 48
+    src = host.make_sample_sources(W, H, 6)
+    cam = host.default_camera(W, H)
+    pt.create_state(W, H, 1000, src, pathtracer.default_params(max_bounces=4, seed=6))
+    pt.set_camera(cam)
+    pt.render_spp(3)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=4, seed=6), 0, 3)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
