@@ -12,7 +12,8 @@ src = host.make_sample_sources(W, H, info.seed, shuffle=2)
 cam = host.default_camera(W, H)
 pt = pathtracer.Pathtracer(0)
 pt.upload_scene(arrays)
-pt.create_state(W, H, W * H * 2, src, pathtracer.default_params(max_bounces=8, seed=info.seed))
+PPP = int(os.environ.get("PPP", "2"))
+pt.create_state(W, H, W * H * PPP, src, pathtracer.default_params(max_bounces=8, seed=info.seed))
 pt.set_camera(cam)
 
 
@@ -39,13 +40,13 @@ def morton_key(rays):
 
 
 pt.step(1)
-r1 = pt.dump_extension_rays(W * H * 2)
+r1 = pt.dump_extension_rays(W * H * PPP)
 print(r1.dtype)
 rate("bounce 1, queue order", r1)
 rng = np.random.default_rng(1)
 rate("bounce 1, shuffled", r1[rng.permutation(len(r1))])
 rate("bounce 1, sorted octant+morton", r1[np.argsort(morton_key(r1), kind="stable")])
 pt.step(1)
-r2 = pt.dump_extension_rays(W * H * 2)
+r2 = pt.dump_extension_rays(W * H * PPP)
 rate("frame 2 queue (bounce 2 + new primary)", r2)
 rate("frame 2, sorted", r2[np.argsort(morton_key(r2), kind="stable")])
