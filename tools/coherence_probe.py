@@ -50,3 +50,18 @@ pt.step(1)
 r2 = pt.dump_extension_rays(W * H * PPP)
 rate("frame 2 queue (bounce 2 + new primary)", r2)
 rate("frame 2, sorted", r2[np.argsort(morton_key(r2), kind="stable")])
+
+
+def chunk_shuffled(rays, chunk):
+    """Sorted rays, then whole chunks of `chunk` consecutive rays in random order: coherent
+    inside a wave's share of work, no expensive region left for the end of the launch."""
+    s = rays[np.argsort(morton_key(rays), kind="stable")]
+    n = len(s) // chunk
+    order = np.random.default_rng(2).permutation(n)
+    idx = (order[:, None] * chunk + np.arange(chunk)[None, :]).reshape(-1)
+    return np.concatenate([s[idx], s[n * chunk:]])
+
+
+for chunk in (128, 1024, 8192, 65536):
+    rate(f"bounce 1, sorted, chunks of {chunk} shuffled", chunk_shuffled(r1, chunk))
+rate("frame 2, sorted, chunks of 128 shuffled", chunk_shuffled(r2, 128))
