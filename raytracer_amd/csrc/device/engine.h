@@ -32,11 +32,10 @@
 
 namespace mirt {
 
-#define MIRT_COOP_LEAF kScanLeafMin
 #ifndef MIRT_REFILL_BELOW
 #define MIRT_REFILL_BELOW 40
 #endif
-constexpr uint32_t kCoopLeaf = MIRT_COOP_LEAF;
+constexpr uint32_t kCoopLeaf = kScanLeafMin;  // leaves this big go to the whole wave (they have scan blocks)
 constexpr int kRefillBelow = MIRT_REFILL_BELOW;  // refill when fewer lanes than this are walking
 #ifndef MIRT_SERVICE_FRAC
 #define MIRT_SERVICE_FRAC 4
