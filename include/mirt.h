@@ -336,6 +336,44 @@ int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax,
 int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                              uint32_t repeats, double *ms_per_launch);
 
+/* ------------------------------------------------- several GPUs, one process */
+
+/* A group is one context per device ordinal, driven from one host thread of
+ * the caller (the shape the reference's single-process host needs; a
+ * process-per-GPU host uses mirt_set_sample_range and the accumulator copies
+ * above with its own collective).  The scene, the state and the camera are
+ * replicated; a render call splits its samples-per-pixel over the members,
+ * which render concurrently; mirt_group_reduce adds the members' integer
+ * accumulators into member 0 (device-to-device copies over xGMI, one add
+ * kernel per member) and clears the others, after which the image is read
+ * from member 0.  Sample numbers are global to the group, so the result is
+ * bit-identical to one context rendering the same number of samples.
+ * No counterpart in the reference, which drives one wgpu device
+ * (src/pathtracer_manager.rs:195-281). */
+typedef struct mirt_group mirt_group;
+
+int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group);
+int mirt_group_destroy(mirt_group *grp);
+int mirt_group_size(const mirt_group *grp);
+/* Member i, for the per-context calls (reads, statistics, ray sets).  NULL when out of range. */
+mirt_ctx *mirt_group_member(mirt_group *grp, int i);
+/* The message of the last failed group call. */
+const char *mirt_group_last_error(const mirt_group *grp);
+/* mirt_scene_upload / mirt_scene_update_instances / mirt_state_create /
+ * mirt_camera_set / mirt_reset_accum on every member. */
+int mirt_group_scene_upload(mirt_group *grp, const MirtSceneDesc *scene);
+int mirt_group_scene_update_instances(mirt_group *grp, const MirtSceneDesc *scene);
+int mirt_group_state_create(mirt_group *grp, uint32_t width, uint32_t height, uint32_t threads,
+                            const MirtSampleSource *sources, uint32_t n_sources,
+                            const MirtParams *params);
+int mirt_group_camera_set(mirt_group *grp, const MirtCamera *camera);
+int mirt_group_reset_accum(mirt_group *grp);
+/* Render `spp` further samples for every source: member i takes spp / n of
+ * them (the first spp % n members one more), all members at once. */
+int mirt_group_render_spp(mirt_group *grp, uint32_t spp);
+/* Member 0 += members 1..n-1, whose accumulators are then cleared. */
+int mirt_group_reduce(mirt_group *grp);
+
 /* -------------------------------------------------------------- diagnostics */
 int mirt_stats(mirt_ctx *ctx, MirtStats *out);
 int mirt_stats_reset(mirt_ctx *ctx);

@@ -6,6 +6,7 @@
 
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -1066,6 +1067,195 @@ int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const floa
   if (e == hipSuccess) e = hipMemcpy(out6, dout, 6 * n * 4, hipMemcpyDeviceToHost);
   free_all(tmp);
   if (e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e));
+  return MIRT_OK;
+}
+
+// ------------------------------------------------------------------ groups
+
+}  // extern "C"
+
+struct mirt_group {
+  std::vector<mirt_ctx *> members;
+  std::string error;
+  uint32_t next_sample = 0;  // the group's sample-number cursor
+  // staging for the reduction, on member 0's device
+  uint32_t *tmp_sum4 = nullptr, *tmp_count = nullptr;
+  size_t tmp_sources = 0;
+};
+
+namespace {
+
+int gfail(mirt_group *g, int status, const std::string &msg) {
+  if (g) g->error = msg;
+  return status;
+}
+
+// Run `call` on every member; the first failure ends the loop and is reported
+// with the member's own message.
+template <class F>
+int for_members(mirt_group *g, const char *what, F call) {
+  if (!g) return MIRT_ERR_INVALID_ARGUMENT;
+  for (size_t i = 0; i < g->members.size(); ++i) {
+    const int rc = call(g->members[i]);
+    if (rc != MIRT_OK)
+      return gfail(g, rc, std::string(what) + ": member " + std::to_string(i) + ": " + mirt_last_error(g->members[i]));
+  }
+  return MIRT_OK;
+}
+
+void group_free_staging(mirt_group *g) {
+  if (g->members.empty()) return;
+  if (hipSetDevice(g->members[0]->device) != hipSuccess) return;
+  if (g->tmp_sum4) (void)hipFree(g->tmp_sum4);
+  if (g->tmp_count) (void)hipFree(g->tmp_count);
+  g->tmp_sum4 = g->tmp_count = nullptr;
+  g->tmp_sources = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group) {
+  if (!device_ordinals || n < 1 || !out_group) return MIRT_ERR_INVALID_ARGUMENT;
+  *out_group = nullptr;
+  mirt_group *g = new (std::nothrow) mirt_group;
+  if (!g) return MIRT_ERR_OUT_OF_MEMORY;
+  for (int i = 0; i < n; ++i) {
+    mirt_ctx *c = nullptr;
+    const int rc = mirt_create(device_ordinals[i], &c);
+    if (rc != MIRT_OK) {
+      for (mirt_ctx *m : g->members) (void)mirt_destroy(m);
+      delete g;
+      return rc;
+    }
+    g->members.push_back(c);
+  }
+  // direct copies between member 0 and the others where the devices allow it
+  // (the reduction works without, through host staging inside the runtime)
+  for (int i = 1; i < n; ++i) {
+    if (device_ordinals[i] == device_ordinals[0]) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device_ordinals[0], device_ordinals[i]) == hipSuccess && can &&
+        hipSetDevice(device_ordinals[0]) == hipSuccess)
+      (void)hipDeviceEnablePeerAccess(device_ordinals[i], 0);  // "already enabled" is fine
+  }
+  (void)hipGetLastError();
+  *out_group = g;
+  return MIRT_OK;
+}
+
+int mirt_group_destroy(mirt_group *g) {
+  if (!g) return MIRT_ERR_INVALID_ARGUMENT;
+  group_free_staging(g);
+  for (mirt_ctx *m : g->members) (void)mirt_destroy(m);
+  delete g;
+  return MIRT_OK;
+}
+
+int mirt_group_size(const mirt_group *g) { return g ? (int)g->members.size() : 0; }
+
+mirt_ctx *mirt_group_member(mirt_group *g, int i) {
+  return (g && i >= 0 && (size_t)i < g->members.size()) ? g->members[(size_t)i] : nullptr;
+}
+
+const char *mirt_group_last_error(const mirt_group *g) { return g ? g->error.c_str() : "null group"; }
+
+int mirt_group_scene_upload(mirt_group *g, const MirtSceneDesc *scene) {
+  return for_members(g, "scene_upload", [&](mirt_ctx *c) { return mirt_scene_upload(c, scene); });
+}
+
+int mirt_group_scene_update_instances(mirt_group *g, const MirtSceneDesc *scene) {
+  return for_members(g, "scene_update_instances", [&](mirt_ctx *c) { return mirt_scene_update_instances(c, scene); });
+}
+
+int mirt_group_state_create(mirt_group *g, uint32_t width, uint32_t height, uint32_t threads,
+                            const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) {
+  const int rc = for_members(g, "state_create", [&](mirt_ctx *c) {
+    return mirt_state_create(c, width, height, threads, sources, n_sources, params);
+  });
+  if (rc == MIRT_OK) g->next_sample = 0;
+  return rc;
+}
+
+int mirt_group_camera_set(mirt_group *g, const MirtCamera *camera) {
+  const int rc = for_members(g, "camera_set", [&](mirt_ctx *c) { return mirt_camera_set(c, camera); });
+  if (rc == MIRT_OK && camera && camera->changed != 0) g->next_sample = 0;  // the members cleared their accumulators
+  return rc;
+}
+
+int mirt_group_reset_accum(mirt_group *g) {
+  const int rc = for_members(g, "reset_accum", [&](mirt_ctx *c) { return mirt_reset_accum(c); });
+  if (rc == MIRT_OK) g->next_sample = 0;
+  return rc;
+}
+
+int mirt_group_render_spp(mirt_group *g, uint32_t spp) {
+  if (!g) return MIRT_ERR_INVALID_ARGUMENT;
+  const size_t n = g->members.size();
+  std::vector<int> rcs(n, MIRT_OK);
+  std::vector<std::thread> workers;
+  uint32_t first = g->next_sample;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t mine = spp / (uint32_t)n + (i < spp % n ? 1u : 0u);
+    if (mine == 0) continue;
+    mirt_ctx *c = g->members[i];
+    int *rc = &rcs[i];
+    // one host thread per member: mirt_render_spp polls its device until the wavefront has drained
+    workers.emplace_back([c, first, mine, rc]() {
+      *rc = mirt_set_sample_range(c, first);
+      if (*rc == MIRT_OK) *rc = mirt_render_spp(c, mine);
+    });
+    first += mine;
+  }
+  for (std::thread &w : workers) w.join();
+  for (size_t i = 0; i < n; ++i)
+    if (rcs[i] != MIRT_OK)
+      return gfail(g, rcs[i], "render_spp: member " + std::to_string(i) + ": " + mirt_last_error(g->members[i]));
+  g->next_sample = first;
+  return MIRT_OK;
+}
+
+int mirt_group_reduce(mirt_group *g) {
+  if (!g) return MIRT_ERR_INVALID_ARGUMENT;
+  mirt_ctx *root = g->members[0];
+  if (!root->have_state) return gfail(g, MIRT_ERR_NOT_READY, "reduce: no state");
+  const size_t ns = root->st.n_sources;
+  for (size_t i = 1; i < g->members.size(); ++i)
+    if (!g->members[i]->have_state || g->members[i]->st.n_sources != ns)
+      return gfail(g, MIRT_ERR_NOT_READY, "reduce: member " + std::to_string(i) + " has no state of the same size");
+  if (g->members.size() == 1) return MIRT_OK;
+#define GROUP_TRY(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) return gfail(g, MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+  GROUP_TRY(hipSetDevice(root->device));
+  if (g->tmp_sources != ns) {
+    group_free_staging(g);
+    GROUP_TRY(hipSetDevice(root->device));
+    GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&g->tmp_sum4), ns * 16));
+    GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&g->tmp_count), ns * 4));
+    g->tmp_sources = ns;
+  }
+  for (size_t i = 1; i < g->members.size(); ++i) {
+    mirt_ctx *c = g->members[i];
+    // the member's own work is complete (render calls synchronise); make sure of it
+    GROUP_TRY(hipSetDevice(c->device));
+    GROUP_TRY(hipStreamSynchronize(c->stream));
+    GROUP_TRY(hipSetDevice(root->device));
+    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum4, root->device, c->st.sum4, c->device, ns * 16, root->stream));
+    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_count, root->device, c->st.count, c->device, ns * 4, root->stream));
+    launch_accum_add(launch_cfg(root), root->st.sum4, g->tmp_sum4, ns * 4);
+    launch_accum_add(launch_cfg(root), root->st.count, g->tmp_count, ns);
+    GROUP_TRY(hipGetLastError());
+    GROUP_TRY(hipStreamSynchronize(root->stream));
+    GROUP_TRY(hipSetDevice(c->device));
+    GROUP_TRY(hipMemsetAsync(c->st.sum4, 0, ns * 16, c->stream));
+    GROUP_TRY(hipMemsetAsync(c->st.count, 0, ns * 4, c->stream));
+    GROUP_TRY(hipStreamSynchronize(c->stream));
+  }
+#undef GROUP_TRY
   return MIRT_OK;
 }
 

@@ -78,6 +78,8 @@ void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DSta
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
+// dst[i] += src[i] for n words (the integer accumulators of another context)
+void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n);
 void launch_init_slots(const LaunchCfg &cfg, const DState &st);
 
 // `work` is a zeroed device word (the launch's chunk cursor).

@@ -449,6 +449,25 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
   if (lane_id() == 0u && shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
 }
 
+// ---------------------------------------------------------- accumulator add
+
+// dst += src, four words per thread (both arrays hold a multiple of four words
+// or end with a scalar tail).
+__global__ __launch_bounds__(256) void k_accum_add(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n) {
+  const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (i + 4u <= n) {
+    uint4 a = *reinterpret_cast<const uint4 *>(dst + i);
+    const uint4 b = *reinterpret_cast<const uint4 *>(src + i);
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    a.w += b.w;
+    *reinterpret_cast<uint4 *>(dst + i) = a;
+  } else {
+    for (size_t k = i; k < n; ++k) dst[k] += src[k];
+  }
+}
+
 // --------------------------------------------------------------- resolve
 
 __device__ __forceinline__ float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
@@ -569,6 +588,12 @@ void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   hipLaunchKernelGGL(k_finish_shade_uber, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+}
+
+void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n) {
+  if (n == 0) return;
+  const size_t threads = (n + 3u) / 4u;
+  hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((threads + 255u) / 256u)), dim3(256), 0, cfg.stream, dst, src, n);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {

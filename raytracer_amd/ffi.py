@@ -216,6 +216,9 @@ DEVICE_SYMBOLS = [
     "mirt_trace_closest", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_stats",
     "mirt_stats_reset", "mirt_set_counting", "mirt_set_event_timing", "mirt_dump_extension_rays",
     "mirt_math_selftest",
+    "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_member", "mirt_group_last_error",
+    "mirt_group_scene_upload", "mirt_group_scene_update_instances", "mirt_group_state_create",
+    "mirt_group_camera_set", "mirt_group_reset_accum", "mirt_group_render_spp", "mirt_group_reduce",
 ]
 
 
@@ -257,5 +260,19 @@ def device_lib():
         L.mirt_set_event_timing.argtypes = [vp, i32]
         L.mirt_dump_extension_rays.argtypes = [vp, vp, sz, C.POINTER(sz)]
         L.mirt_math_selftest.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.mirt_group_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+        L.mirt_group_destroy.argtypes = [vp]
+        L.mirt_group_size.argtypes = [vp]
+        L.mirt_group_member.restype = vp
+        L.mirt_group_member.argtypes = [vp, i32]
+        L.mirt_group_last_error.restype = C.c_char_p
+        L.mirt_group_last_error.argtypes = [vp]
+        L.mirt_group_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.mirt_group_scene_update_instances.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.mirt_group_state_create.argtypes = [vp, u32, u32, u32, vp, u32, C.POINTER(Params)]
+        L.mirt_group_camera_set.argtypes = [vp, vp]
+        L.mirt_group_reset_accum.argtypes = [vp]
+        L.mirt_group_render_spp.argtypes = [vp, u32]
+        L.mirt_group_reduce.argtypes = [vp]
         _device = L
     return _device

@@ -26,19 +26,24 @@ def default_params(**kw):
 
 
 class Pathtracer:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._L = ffi.device_lib()
-        h = C.c_void_p()
-        rc = self._L.mirt_create(device, C.byref(h))
-        if rc != 0:
-            raise MirtError(f"mirt_create(device={device}): {self._L.mirt_status_string(rc).decode()}")
-        self._h = h
+        self._owned = _borrowed is None
+        if _borrowed is not None:  # a member of a PathtracerGroup, which owns the context
+            self._h = C.c_void_p(_borrowed)
+        else:
+            h = C.c_void_p()
+            rc = self._L.mirt_create(device, C.byref(h))
+            if rc != 0:
+                raise MirtError(f"mirt_create(device={device}): {self._L.mirt_status_string(rc).decode()}")
+            self._h = h
         self.n_sources = 0
         self.width = self.height = 0
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.mirt_destroy(self._h)
+            if self._owned:
+                self._L.mirt_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -179,3 +184,81 @@ def partition_samples(spp, world_size, rank):
     n = base + (1 if rank < extra else 0)
     first = rank * base + min(rank, extra)
     return first, n
+
+
+class PathtracerGroup:
+    """Several GPUs driven from one process (mirt_group_*): scene, state and camera are
+    replicated, a render call splits its samples-per-pixel over the members, reduce() adds
+    the members' accumulators into member 0, which the reads go through."""
+
+    def __init__(self, devices):
+        self._L = ffi.device_lib()
+        ords = (C.c_int32 * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self._L.mirt_group_create(ords, len(devices), C.byref(g))
+        if rc != 0:
+            raise MirtError(f"mirt_group_create({list(devices)}): {self._L.mirt_status_string(rc).decode()}")
+        self._g = g
+        self.members = [Pathtracer(_borrowed=self._L.mirt_group_member(g, i)) for i in range(len(devices))]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()
+            self._L.mirt_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __len__(self):
+        return self._L.mirt_group_size(self._g)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MirtError(f"{what}: {self._L.mirt_status_string(rc).decode()}: "
+                            f"{self._L.mirt_group_last_error(self._g).decode()}")
+
+    def upload_scene(self, arrays):
+        d = ffi.desc_from_arrays(arrays)
+        self._check(self._L.mirt_group_scene_upload(self._g, C.byref(d)), "mirt_group_scene_upload")
+
+    def update_instances(self, arrays):
+        d = ffi.desc_from_arrays(arrays)
+        self._check(self._L.mirt_group_scene_update_instances(self._g, C.byref(d)), "mirt_group_scene_update_instances")
+
+    def create_state(self, width, height, threads, sources, params):
+        sources = np.ascontiguousarray(sources, ffi.SampleSource)
+        self._check(self._L.mirt_group_state_create(self._g, width, height, threads, sources.ctypes.data, len(sources),
+                                                    C.byref(params)), "mirt_group_state_create")
+        for m in self.members:
+            m.n_sources = len(sources)
+            m.width, m.height = width, height
+
+    def set_camera(self, camera):
+        cam = np.ascontiguousarray(camera, ffi.Camera)
+        self._check(self._L.mirt_group_camera_set(self._g, cam.ctypes.data), "mirt_group_camera_set")
+
+    def reset_accum(self):
+        self._check(self._L.mirt_group_reset_accum(self._g), "mirt_group_reset_accum")
+
+    def render_spp(self, spp):
+        self._check(self._L.mirt_group_render_spp(self._g, spp), "mirt_group_render_spp")
+
+    def reduce(self):
+        self._check(self._L.mirt_group_reduce(self._g), "mirt_group_reduce")
+
+    def read_accum(self):
+        return self.members[0].read_accum()
+
+    def read_output(self):
+        return self.members[0].read_output()

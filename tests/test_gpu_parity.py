@@ -580,3 +580,48 @@ def test_whole_wave_leaves_of_every_block_shape(pt):
     s4, cnt = pt.read_accum()
     w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=4, seed=6), 0, 3)
     assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+
+
+def test_group_of_contexts_splits_samples_and_reduces_bit_exactly(config_scenes):
+    """mirt_group_*: three contexts (all on device 0 here; one per GPU on a node), samples
+    split 2 + 2 + 1 and then 2 + 1 + 1, integer reduction into member 0 — the same sums as
+    one context and as the oracle rendering 9 samples."""
+    arrays, info = config_scenes(1)
+    W, H = 96, 64
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=4, seed=info.seed)
+    with pathtracer.PathtracerGroup([0, 0, 0]) as grp:
+        assert len(grp) == 3
+        grp.upload_scene(arrays)
+        grp.create_state(W, H, 3000, src, prm)
+        grp.set_camera(cam)
+        grp.render_spp(5)
+        parts = [m.read_accum() for m in grp.members]
+        assert [int(c.sum()) for _, c in parts] == [2 * W * H, 2 * W * H, W * H]
+        grp.reduce()
+        s5, c5 = grp.read_accum()
+        assert np.array_equal(s5, parts[0][0] + parts[1][0] + parts[2][0]) and np.array_equal(c5, np.full(W * H, 5, "<u4"))
+        for m in grp.members[1:]:  # cleared, so that a second reduction adds nothing twice
+            s, c = m.read_accum()
+            assert not s.any() and not c.any()
+        grp.render_spp(4)
+        grp.reduce()
+        s9, c9 = grp.read_accum()
+        pixels = grp.read_output()
+    with pathtracer.Pathtracer(0) as one:
+        one.upload_scene(arrays)
+        one.create_state(W, H, 3000, src, prm)
+        one.set_camera(cam)
+        one.render_spp(9)
+        w4, wc = one.read_accum()
+        wpix = one.read_output()
+    assert np.array_equal(s9, w4) and np.array_equal(c9, wc) and np.array_equal(pixels, wpix)
+    o4, oc, _ = po.Scene(arrays).render(cam, src, W, H, po.default_params(max_bounces=4, seed=info.seed), 0, 9)
+    assert np.array_equal(s9, o4) and np.array_equal(c9, oc)
+    # errors carry the member and its message
+    with pathtracer.PathtracerGroup([0]) as g1:
+        with pytest.raises(pathtracer.MirtError, match="member 0"):
+            g1.render_spp(1)
+    with pytest.raises(pathtracer.MirtError):
+        pathtracer.PathtracerGroup([9999])
