@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--paths-per-pixel", type=int, default=16,
+    ap.add_argument("--paths-per-pixel", type=int, default=32,
                     help="paths in flight (slots of the wavefront state) per pixel")
     ap.add_argument("--config", type=int, default=3)
     ap.add_argument("--width", type=int, default=0)
