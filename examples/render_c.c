@@ -4,7 +4,11 @@
  *
  *   cc examples/render_c.c -Iinclude -Lraytracer_amd/lib -lmirt -lmirt_host \
  *      -Wl,-rpath,$PWD/raytracer_amd/lib -o build/render_c
- *   build/render_c <asset_dir> <config 1..5> <spp> <out.ppm> [width height]
+ *   build/render_c <asset_dir> <config 1..5> <spp> <out.ppm> [width height [members]]
+ *
+ * With `members` > 1 the same render goes through a group of that many contexts
+ * (MIRT_GROUP_DEVICES="0,1,..." names their devices; default: all on device 0),
+ * which split the samples and add their accumulators up; the output is the same.
  *
  * Prints "checksum <sum of all fixed-point radiance sums> samples <n>". */
 #include <stdint.h>
@@ -25,7 +29,7 @@
 
 int main(int argc, char **argv) {
   if (argc < 5) {
-    fprintf(stderr, "usage: %s <asset_dir> <config 1..5> <spp> <out.ppm> [width height]\n", argv[0]);
+    fprintf(stderr, "usage: %s <asset_dir> <config 1..5> <spp> <out.ppm> [width height [members]]\n", argv[0]);
     return 2;
   }
   const char *asset_dir = argv[1];
@@ -52,18 +56,49 @@ int main(int argc, char **argv) {
   camera.dims[1] = 1.0f;
 
   /* device side */
-  mirt_ctx *ctx = NULL;
-  CHECK(ctx, mirt_create(0, &ctx));
-  CHECK(ctx, mirt_scene_upload(ctx, &desc));
   MirtParams params;
   mirt_default_params(&params);
   params.max_bounces = info.max_bounces;
   params.shade_mode = info.shade_mode;
   params.nee = info.nee;
   params.seed = info.seed;
-  CHECK(ctx, mirt_state_create(ctx, width, height, (uint32_t)n_pixels, sources, (uint32_t)n_pixels, &params));
-  CHECK(ctx, mirt_camera_set(ctx, &camera));
-  CHECK(ctx, mirt_render_spp(ctx, spp));
+  const int members = argc > 7 ? atoi(argv[7]) : 1;
+  mirt_ctx *ctx = NULL;
+  mirt_group *grp = NULL;
+  if (members > 1) {
+    /* one process, several GPUs: replicate, split the samples, reduce into member 0 */
+    int ordinals[64] = {0};
+    const char *list = getenv("MIRT_GROUP_DEVICES");
+    for (int i = 0; i < members && i < 64; ++i) {
+      ordinals[i] = list ? atoi(list) : 0;
+      if (list) {
+        while (*list && *list != ',') ++list;
+        if (*list == ',') ++list;
+        if (!*list) list = NULL;
+      }
+    }
+    CHECK(ctx, mirt_group_create(ordinals, members < 64 ? members : 64, &grp));
+#define GCHECK(call)                                                                             \
+  do {                                                                                           \
+    int rc_ = (call);                                                                            \
+    if (rc_ != 0) {                                                                              \
+      fprintf(stderr, "%s: %s (%s)\n", #call, mirt_status_string(rc_), mirt_group_last_error(grp)); \
+      return 1;                                                                                  \
+    }                                                                                            \
+  } while (0)
+    GCHECK(mirt_group_scene_upload(grp, &desc));
+    GCHECK(mirt_group_state_create(grp, width, height, (uint32_t)n_pixels, sources, (uint32_t)n_pixels, &params));
+    GCHECK(mirt_group_camera_set(grp, &camera));
+    GCHECK(mirt_group_render_spp(grp, spp));
+    GCHECK(mirt_group_reduce(grp));
+    ctx = mirt_group_member(grp, 0); /* the reads below go through member 0 */
+  } else {
+    CHECK(ctx, mirt_create(0, &ctx));
+    CHECK(ctx, mirt_scene_upload(ctx, &desc));
+    CHECK(ctx, mirt_state_create(ctx, width, height, (uint32_t)n_pixels, sources, (uint32_t)n_pixels, &params));
+    CHECK(ctx, mirt_camera_set(ctx, &camera));
+    CHECK(ctx, mirt_render_spp(ctx, spp));
+  }
 
   uint32_t *rgb = malloc(n_pixels * sizeof *rgb);
   uint32_t *sum4 = malloc(4 * n_pixels * sizeof *sum4), *count = malloc(n_pixels * sizeof *count);
@@ -89,7 +124,8 @@ int main(int argc, char **argv) {
   }
   fclose(f);
 
-  mirt_destroy(ctx);
+  if (grp) mirt_group_destroy(grp);
+  else mirt_destroy(ctx);
   mirth_scene_free(scene);
   free(sources);
   free(rgb);

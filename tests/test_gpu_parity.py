@@ -383,6 +383,12 @@ def test_plain_c_driver_renders_the_same_sums(pt, config_scenes, tmp_path):
     assert int(words[1]) == want and int(words[3]) == int(cnt.sum()) == W * H * spp
     ppm = open(tmp_path / "c.ppm", "rb").read()
     assert ppm.startswith(b"P6\n96 64\n255\n") and len(ppm) == len(b"P6\n96 64\n255\n") + 3 * W * H
+    # the same render through a group of two contexts (mirt_group_*): same sums, same image
+    out2 = subprocess.run([exe, assets, "1", str(spp), str(tmp_path / "g.ppm"), str(W), str(H), "2"], capture_output=True,
+                          text=True, timeout=100)
+    assert out2.returncode == 0, out2.stderr
+    assert out2.stdout.split() == words
+    assert open(tmp_path / "g.ppm", "rb").read() == ppm
 
 
 def _three_suzannes(moved):
