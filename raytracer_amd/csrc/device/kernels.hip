@@ -76,12 +76,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
       const float4 a = reinterpret_cast<const float4 *>(pp)[0];
       const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
       if (source != kNoSample) {
-#ifndef MIRT_EXPERIMENT_NO_ACCUM
         atomicAdd(&st.count[source], 1u);
         atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(a.x, fp.p.fixed_point_scale));
         atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(a.y, fp.p.fixed_point_scale));
         atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(a.z, fp.p.fixed_point_scale));
-#endif
         finished++;
       }
     }
