@@ -186,7 +186,7 @@ enum : uint32_t {
 static_assert(F_HOLD == F_WRAP << 2, "the triangle step derives F_HOLD from F_WRAP with a shift");
 
 #ifndef MIRT_STEPS_PER_CHECK
-#define MIRT_STEPS_PER_CHECK 4
+#define MIRT_STEPS_PER_CHECK 8
 #endif
 constexpr int kStepsPerCheck = MIRT_STEPS_PER_CHECK;  // steps between two looks at the service condition
 
