@@ -631,3 +631,44 @@ def test_group_of_contexts_splits_samples_and_reduces_bit_exactly(config_scenes)
             g1.render_spp(1)
     with pytest.raises(pathtracer.MirtError):
         pathtracer.PathtracerGroup([9999])
+
+
+def test_axis_aligned_rays_from_box_planes_nan_semantics(pt):
+    """Rays with zero direction components whose origins lie exactly on box planes: the slab
+    test then multiplies 0 by infinity, and what min / max do with the NaN decides the walk
+    (rayBoxIntersect, shaders/ray_extend.slang:94-111; here: the NaN is ignored).  Hit ids,
+    t bits and visit counts must still be the oracle's."""
+    arrays = _comb_scene([3, 30, 4, 70, 2, 4, 1, 90], 21)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    nodes = arrays["blas_nodes"]
+    rng = np.random.default_rng(22)
+    n = 24000
+    pick = rng.integers(0, len(nodes), n)
+    corner = rng.integers(0, 2, (n, 3)).astype(bool)
+    pos = np.where(corner, nodes["ub"][pick][:, :3], nodes["lb"][pick][:, :3]).astype("<f4")
+    # a third of the origins are pushed off the planes along one axis, so that rays also start outside
+    off = rng.integers(0, 3, n)
+    pos[np.arange(n), off] += np.where(rng.random(n) < 0.33, rng.choice(np.float32([-3.0, 3.0]), n), np.float32(0.0))
+    d = np.zeros((n, 3), "<f4")
+    kind = rng.integers(0, 3, n)
+    axis = rng.integers(0, 3, n)
+    sign = rng.choice(np.float32([-1.0, 1.0]), n)
+    d[np.arange(n), axis] = sign                                    # one non-zero component
+    two = kind >= 1                                                 # two non-zero components
+    d[np.arange(n)[two], (axis[two] + 1) % 3] = rng.normal(size=two.sum()).astype("<f4")
+    neg0 = kind == 2                                                # the zero component is -0.0: 1/dir = -inf
+    d[np.arange(n)[neg0], (axis[neg0] + 2) % 3] = np.float32(-0.0)
+    rays = np.zeros(n, ffi.Ray)
+    rays["pos"], rays["dir"] = pos, d
+    rays["last_inst"] = ffi.NO_PRIM
+    rays["last_prim"] = ffi.NO_PRIM
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want) and gc.as_dict() == wc.as_dict()
+    hit = want["instance_id"] != ffi.NO_HIT
+    assert 500 < hit.sum() < n
+    tmax = np.full(n, 1.5, "<f4")
+    want_any, wca = sc.trace_any(rays, tmax, True)
+    got_any, gca = pt.trace_any(rays, tmax, True)
+    assert hits_equal(got_any, want_any) and gca.as_dict() == wca.as_dict()
