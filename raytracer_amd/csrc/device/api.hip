@@ -5,8 +5,10 @@
 #include <string.h>
 
 #include <new>
+#include <algorithm>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -494,6 +496,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   struct ScanLeaf {
     uint32_t first_tri, count;
     size_t block;
+    uint32_t vertex_base;  // of its geometry, for the index rows
   };
   std::vector<ScanLeaf> scan_leaves;
   size_t scan_blocks = 0;
@@ -544,7 +547,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       if (tag == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
       if (tag >= kScanLeafMin) {
         const uint32_t cnt = tag == kBigLeaf ? sizes[i] : tag;
-        scan_leaves.push_back(ScanLeaf{o.index + dn.a, cnt, scan_blocks});
+        scan_leaves.push_back(ScanLeaf{o.index + dn.a, cnt, scan_blocks, o.vertex});
         scan_blocks += (cnt + 63u) / 64u;
       }
     }
@@ -574,6 +577,52 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       memcpy(blk + 2048u + lane * 4u, &t.e2z, 4);
     }
   }
+  // LDS leaf cache: the biggest scanned leaves first, as long as their vertices
+  // and index rows fit the image.
+  std::vector<uint4> cache_image;
+  {
+    std::vector<const ScanLeaf *> order;
+    for (const ScanLeaf &sl : scan_leaves) order.push_back(&sl);
+    std::stable_sort(order.begin(), order.end(), [](const ScanLeaf *a, const ScanLeaf *b) { return a->count > b->count; });
+    std::unordered_map<uint32_t, uint32_t> slot_of;  // global vertex index -> vertex number in the image
+    std::vector<uint32_t> image_vertices;            // global vertex index of every image vertex
+    std::vector<const ScanLeaf *> taken;
+    size_t taken_tris = 0;
+    for (const ScanLeaf *sl : order) {
+      std::vector<uint32_t> fresh;
+      for (uint32_t k = 0; k < sl->count; ++k)
+        for (int j = 0; j < 3; ++j) {
+          const uint32_t v = sl->vertex_base + d->indices[sl->first_tri + k].v[j];
+          if (!slot_of.count(v) && std::find(fresh.begin(), fresh.end(), v) == fresh.end()) fresh.push_back(v);
+        }
+      const size_t nv = image_vertices.size() + fresh.size();
+      if (nv > 65536u || nv * 16u + (taken_tris + sl->count) * 8u > kLeafCacheBytes) continue;
+      for (uint32_t v : fresh) {
+        slot_of[v] = (uint32_t)image_vertices.size();
+        image_vertices.push_back(v);
+      }
+      taken.push_back(sl);
+      taken_tris += sl->count;
+    }
+    if (!taken.empty()) {
+      const size_t vert_bytes = image_vertices.size() * 16u;
+      cache_image.assign((vert_bytes + taken_tris * 8u + 15u) / 16u, uint4{0u, 0u, 0u, 0u});
+      unsigned char *img = reinterpret_cast<unsigned char *>(cache_image.data());
+      for (size_t i = 0; i < image_vertices.size(); ++i) memcpy(img + i * 16u, d->vertices[image_vertices[i]].position, 12);
+      size_t at = vert_bytes;
+      for (const ScanLeaf *sl : taken) {
+        tris[sl->first_tri].e2w = (uint32_t)at + 1u;
+        for (uint32_t k = 0; k < sl->count; ++k) {
+          const MirtIndex &f = d->indices[sl->first_tri + k];
+          const uint32_t v0 = slot_of[sl->vertex_base + f.v[0]], v1 = slot_of[sl->vertex_base + f.v[1]],
+                         v2 = slot_of[sl->vertex_base + f.v[2]];
+          const uint32_t row[2] = {v0 | (v1 << 16), v2};
+          memcpy(img + at, row, 8);
+          at += 8u;
+        }
+      }
+    }
+  }
   memcpy(geo.data(), nodes.data(), node_bytes);
   if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
   const unsigned char *pg = nullptr;
@@ -584,6 +633,9 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   sc.tri_off = (uint32_t)tri_off;
   sc.nodes = reinterpret_cast<const DNode *>(pg);
   sc.tri = reinterpret_cast<const DTri *>(pg + tri_off);
+  sc.leaf_cache = nullptr;
+  sc.leaf_cache_bytes = (uint32_t)(cache_image.size() * 16u);
+  if (!cache_image.empty() && (rc = dev_upload(ctx, ctx->scene_allocs, &sc.leaf_cache, cache_image)) != MIRT_OK) return rc;
   return dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
 }
 

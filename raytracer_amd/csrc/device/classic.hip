@@ -80,7 +80,7 @@ __device__ __forceinline__ float lambert_pdf(v3 wi, v3 n) { return fmax_nn(0.0f,
 // shadow ray as an any-hit query, writes the slot's ShadowData and routes the
 // slot to the queue of its hit material.
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_connect(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kEngineBlock) void k_connect(DScene sc, DState st, DFrameParams fp) {
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
   LaneCounts lc;
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st,
 
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
-  if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_connect<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_connect<false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
   hipLaunchKernelGGL(k_connect_finish, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 

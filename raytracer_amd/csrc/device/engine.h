@@ -169,7 +169,15 @@ struct WorkSource {
 #define MIRT_PH_FLUSH(ptr)
 #endif
 
-constexpr uint32_t kEngineBlock = 256u;  // threads per block of every kernel built on the engine
+#ifndef MIRT_ENGINE_BLOCK
+#define MIRT_ENGINE_BLOCK 1024u
+#endif
+// Threads per block of every kernel built on the engine.  One 1024-thread block
+// per CU (four waves per SIMD): the per-thread state takes 80 KB of LDS and the
+// leaf cache, which every wave of the CU shares, up to 64 KB more.
+constexpr uint32_t kEngineBlock = MIRT_ENGINE_BLOCK;
+// the leaf cache needs the one-block-per-CU shape; smaller blocks go without
+constexpr uint32_t kLeafCacheWords16 = kEngineBlock == 1024u ? kLeafCacheBytes / 16u : 0u;
 constexpr uint32_t kNoExclude = 0xFFFFFFFFu;
 
 // Per-lane walk flags, kept in one vector register: as lane masks in scalar
@@ -236,7 +244,13 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   __shared__ uint32_t s_tag[3][kEngineBlock];   // last_inst, last_prim, payload
   __shared__ uint32_t s_best[4][kEngineBlock];  // u bits, v bits, prim, inst
   __shared__ uint32_t s_tlas[4][kEngineBlock];  // while in a BLAS: TLAS cursor, next slot, end of the slot range, instance
+  __shared__ uint4 s_cache[kLeafCacheWords16 ? kLeafCacheWords16 : 1u];  // the scene's leaf-cache image (layout.h)
   const uint32_t tid = threadIdx.x;
+  if (kLeafCacheWords16 != 0u) {
+    const uint32_t n16 = sc.leaf_cache_bytes / 16u < kLeafCacheWords16 ? sc.leaf_cache_bytes / 16u : kLeafCacheWords16;
+    for (uint32_t i = tid; i < n16; i += kEngineBlock) s_cache[i] = sc.leaf_cache[i];
+    __syncthreads();
+  }
   const uint32_t lane = trv_lane();
   const BufferRsrc geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(sc.geo), 0, (int)sc.geo_bytes, 0x00020000);
   const uint32_t tlas_nbase = sc.tlas_base * 32u;
@@ -297,22 +311,16 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
           const uint32_t otbase = bcast_u(tbase);
           uint32_t ocount = bcast_u(leaf_count);
           if (ocount == kBigLeaf) ocount = geo_load4(geo, otbase + ostart * 48u + 12u);  // size stored out of line
-          const uint32_t oblocks = geo_load4(geo, otbase + ostart * 48u + 28u);  // the leaf's scan blocks
           const uint32_t oskip = bcast_u(excl_prim);
           // per-lane best over triangles ostart + lane, + 64, ...
           // key: ANY -> index (first accepted in index order);
           //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
           unsigned long long key = ~0ull;
           float ku = 0.0f, kv = 0.0f, kt = 0.0f;
-          uint32_t boff = oblocks + lane * 16u;
-          for (uint32_t k = lane; k < ocount; k += 64u, boff += kScanBlockBytes) {
-            const uint32_t p = ostart + k;
-            if (p == oskip) continue;
-            const float4 a0 = geo_load16(geo, boff), a1 = geo_load16(geo, boff + 1024u);
-            const float a2 = __uint_as_float(geo_load4(geo, boff + 2048u - lane * 12u));
+          // one triangle for this lane; returns true when the lane needs no further ones
+          auto consider = [&](uint32_t p, v3 p0, v3 e1, v3 e2) {
             float t2, u, v;
-            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a0.w, a1.x, a1.y), V3(a1.z, a1.w, a2), t2, u, v) &&
-                !(t2 > ot || t2 < 0.0f)) {
+            if (ray_tri_uvt(op, od, p0, e1, e2, t2, u, v) && !(t2 > ot || t2 < 0.0f)) {
               const unsigned long long kk =
                   ANY ? (unsigned long long)p
                       : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
@@ -322,7 +330,33 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
                 kv = v;
                 kt = t2;
               }
-              if (ANY) break;  // later triangles of this lane have higher indices
+              return ANY;  // later triangles of this lane have higher indices
+            }
+            return false;
+          };
+          const uint32_t ocached = kLeafCacheWords16 != 0u ? geo_load4(geo, otbase + ostart * 48u + 44u) : 0u;
+          if (ocached != 0u) {
+            // the leaf is in LDS: three 16-bit vertex numbers per triangle, e1 and e2 rebuilt
+            // with the subtractions the upload does for DTri
+            const uint2 *rows = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(s_cache) + (ocached - 1u));
+            for (uint32_t k = lane; k < ocount; k += 64u) {
+              const uint32_t p = ostart + k;
+              if (p == oskip) continue;
+              const uint2 row = rows[k];
+              const uint4 q0 = s_cache[row.x & 0xFFFFu], q1 = s_cache[row.x >> 16], q2 = s_cache[row.y];
+              const v3 p0 = V3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+              const v3 p1 = V3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+              const v3 p2 = V3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+              if (consider(p, p0, sub3(p1, p0), sub3(p2, p0))) break;
+            }
+          } else {
+            uint32_t boff = geo_load4(geo, otbase + ostart * 48u + 28u) + lane * 16u;  // the leaf's scan blocks
+            for (uint32_t k = lane; k < ocount; k += 64u, boff += kScanBlockBytes) {
+              const uint32_t p = ostart + k;
+              if (p == oskip) continue;
+              const float4 a0 = geo_load16(geo, boff), a1 = geo_load16(geo, boff + 1024u);
+              const float a2 = __uint_as_float(geo_load4(geo, boff + 2048u - lane * 12u));
+              if (consider(p, V3(a0.x, a0.y, a0.z), V3(a0.w, a1.x, a1.y), V3(a1.z, a1.w, a2))) break;
             }
           }
           unsigned long long wkey = key;

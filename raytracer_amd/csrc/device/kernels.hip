@@ -166,7 +166,7 @@ constexpr uint32_t kMissInst = 0xFFFFFFFFu;
 #endif
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, MIRT_EXTEND_WAVES) void k_extend(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_resolve(DState st, DFrameParams fp) {
 // ----------------------------------------------------------------- trace
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(256) void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
+__global__ __launch_bounds__(kEngineBlock) void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
                                                MirtHitId *out, unsigned long long *counts5, uint32_t *work) {
   LaneCounts lc;
   auto fetch = [&](uint32_t idx, RayIn &r) {
@@ -556,19 +556,20 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
   hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, st, fp);
 }
 
-#ifndef MIRT_ENGINE_BLOCKS
-#define MIRT_ENGINE_BLOCKS 5
+// resident waves per SIMD the engine kernels are launched with (blocks per CU x waves per block / 4)
+#ifndef MIRT_ENGINE_WAVES
+#define MIRT_ENGINE_WAVES 5
 #endif
-constexpr int kEngineBlocksPerCU = MIRT_ENGINE_BLOCKS;
+constexpr int kEngineBlocksPerCU = (MIRT_ENGINE_WAVES * 256) / (int)kEngineBlock > 0 ? (MIRT_ENGINE_WAVES * 256) / (int)kEngineBlock : 1;
 
 int trace_grid_blocks(int num_cus) {
   static int per_cu = 0;
   if (per_cu == 0) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, 256, 0) != hipSuccess || n < 1) n = 4;
-    // The engine is bound by instruction issue, which three to four waves per
-    // SIMD saturate; more resident waves only mean fewer rays per wave and a
-    // longer drain, so the grid stops at kEngineBlocksPerCU blocks per CU.
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, (int)kEngineBlock, 0) != hipSuccess || n < 1) n = 4;
+    // Four to five waves per SIMD are enough to keep the memory path busy; more
+    // resident waves only mean fewer rays per wave and a longer drain, so the
+    // grid stops at kEngineBlocksPerCU blocks per CU.
     per_cu = n > kEngineBlocksPerCU ? kEngineBlocksPerCU : n;
   }
   return per_cu * num_cus;
@@ -576,8 +577,8 @@ int trace_grid_blocks(int num_cus) {
 
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
-  if (fp.counting) hipLaunchKernelGGL((k_extend<true>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_extend<false>), grid, dim3(256), 0, cfg.stream, sc, st, fp);
+  if (fp.counting) hipLaunchKernelGGL((k_extend<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_extend<false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
@@ -607,11 +608,11 @@ void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, cons
   const dim3 grid((unsigned)(want < (size_t)full ? want : (size_t)full));
   const uint32_t n32 = (uint32_t)n;
   if (any_hit) {
-    if (counting) hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
-    else hipLaunchKernelGGL((k_trace<true, false>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    if (counting) hipLaunchKernelGGL((k_trace<true, true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    else hipLaunchKernelGGL((k_trace<true, false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
   } else {
-    if (counting) hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
-    else hipLaunchKernelGGL((k_trace<false, false>), grid, dim3(256), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    if (counting) hipLaunchKernelGGL((k_trace<false, true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
+    else hipLaunchKernelGGL((k_trace<false, false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, rays, tmax, n32, out, counts5, work);
   }
 }
 

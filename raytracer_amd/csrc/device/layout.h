@@ -54,7 +54,8 @@ struct DTri {
   uint32_t p0w;  // out-of-line leaf size for the first triangle of a big leaf
   float e1x, e1y, e1z;
   uint32_t e1w;  // first triangle of a leaf the whole wave scans: byte offset of its scan blocks
-  float e2x, e2y, e2z, e2w;
+  float e2x, e2y, e2z;
+  uint32_t e2w;  // first triangle of a leaf held in the LDS leaf cache: byte offset of its index array in the image + 1
 };
 
 // Leaves with kScanLeafMin or more triangles are tested by a whole wave, 64
@@ -66,6 +67,18 @@ struct DTri {
 #endif
 constexpr uint32_t kScanLeafMin = MIRT_SCAN_LEAF_MIN;
 constexpr uint32_t kScanBlockBytes = 2304u;
+
+// The largest of those leaves are also kept in LDS by the traversal kernels
+// (their blocks would otherwise be streamed from the L2 by every ray that
+// reaches them): one image of at most kLeafCacheBytes, copied into LDS when a
+// block starts.  Image: the unique vertices of the cached leaves (float4 each,
+// w unused), then per leaf one uint2 per triangle holding three 16-bit vertex
+// numbers (x = v0 | v1 << 16, y = v2).  The kernel rebuilds e1 = p1 - p0 and
+// e2 = p2 - p0 with the same f32 subtractions the upload does for DTri.
+#ifndef MIRT_LEAF_CACHE_KB
+#define MIRT_LEAF_CACHE_KB 64u
+#endif
+constexpr uint32_t kLeafCacheBytes = MIRT_LEAF_CACHE_KB * 1024u;
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
 
 struct DTriN {
@@ -137,6 +150,8 @@ struct DScene {
   const DInst *inst;
   const DTri *tri;            // = geo + tri_off
   const DTriN *trin;
+  const uint4 *leaf_cache;    // image of the LDS leaf cache (see kLeafCacheBytes)
+  uint32_t leaf_cache_bytes;  // multiple of 16, 0 when no leaf is cached
   const DMaterial *mat;
   const uint32_t *lights;     // instance ids
   uint32_t n_lights;          // 0 when the scene has none
