@@ -9,6 +9,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "kernels.h"
@@ -589,11 +590,14 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     std::vector<const ScanLeaf *> taken;
     size_t taken_tris = 0;
     for (const ScanLeaf *sl : order) {
-      std::vector<uint32_t> fresh;
-      for (uint32_t k = 0; k < sl->count; ++k)
+      if ((taken_tris + sl->count) * 8u > kLeafCacheBytes) continue;
+      std::vector<uint32_t> fresh;  // vertices this leaf would add, in order of first use
+      std::unordered_set<uint32_t> fresh_set;
+      const size_t max_vertices = kLeafCacheBytes / 16u;
+      for (uint32_t k = 0; k < sl->count && image_vertices.size() + fresh.size() <= max_vertices; ++k)
         for (int j = 0; j < 3; ++j) {
           const uint32_t v = sl->vertex_base + d->indices[sl->first_tri + k].v[j];
-          if (!slot_of.count(v) && std::find(fresh.begin(), fresh.end(), v) == fresh.end()) fresh.push_back(v);
+          if (!slot_of.count(v) && fresh_set.insert(v).second) fresh.push_back(v);
         }
       const size_t nv = image_vertices.size() + fresh.size();
       if (nv > 65536u || nv * 16u + (taken_tris + sl->count) * 8u > kLeafCacheBytes) continue;
