@@ -65,8 +65,8 @@ struct LaunchCfg {
   int num_cus;      // the ray-tracing kernels launch a persistent grid sized from this
 };
 
-// Blocks of 256 threads that fill the device for the closest-hit engine
-// (resident blocks per CU from the occupancy query, times CUs).
+// Blocks of kEngineBlock threads that fill the device for the traversal engine
+// (resident blocks per CU from the occupancy query — one — times CUs).
 int trace_grid_blocks(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);

@@ -158,12 +158,9 @@ __global__ __launch_bounds__(256) void k_init_slots(DState st) {
 // every entry of this frame's extension queue.  It leaves the raw result in the
 // slot's hit record — u, v, t and the instance (kMissInst when nothing was hit)
 // in the first 16 bytes, the triangle id in the last word — for
-// k_extend_finish; keeping the epilogue out of this kernel keeps its register
-// count at eight waves per SIMD.
+// the streaming kernel that follows; keeping the epilogue out of this kernel
+// keeps its registers and instruction footprint small.
 constexpr uint32_t kMissInst = 0xFFFFFFFFu;
-#ifndef MIRT_EXTEND_WAVES
-#define MIRT_EXTEND_WAVES 5  // waves per SIMD the register allocation must allow
-#endif
 
 template <bool COUNT>
 __global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, DFrameParams fp) {
