@@ -383,9 +383,13 @@ int seed_slots(mirt_ctx *c) {
   return MIRT_OK;
 }
 
-void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample) {
+// `respawn` (uber shading only): the shade kernel accumulates and respawns the
+// paths that end, so after the first frame the sample kernel finds an empty
+// terminate queue and only clears the idle queue counters.
+void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample, bool respawn) {
   const LaunchCfg cfg = launch_cfg(c);
-  const DFrameParams fp = frame_params(c, sample_limit, first_sample);
+  DFrameParams fp = frame_params(c, sample_limit, first_sample);
+  fp.respawn = respawn && c->params.shade_mode != MIRT_SHADE_CLASSIC ? 1u : 0u;
   timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
   if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
@@ -852,7 +856,7 @@ int mirt_step(mirt_ctx *ctx, uint32_t n_frames) {
   if (rc != MIRT_OK) return rc;
   if (!ctx->slots_seeded && (rc = seed_slots(ctx)) != MIRT_OK) return rc;
   // samples keep regenerating: no limit on the number handed out
-  for (uint32_t f = 0; f < n_frames; ++f) run_frame(ctx, ~0ull, ctx->next_sample);
+  for (uint32_t f = 0; f < n_frames; ++f) run_frame(ctx, ~0ull, ctx->next_sample, false);
   return MIRT_OK;
 }
 
@@ -877,7 +881,7 @@ int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
   const unsigned long long max_frames = rounds * ((unsigned long long)ctx->params.max_bounces + 2ull) + 8ull;
   unsigned long long frames = 0;
   while (true) {
-    for (uint32_t f = 0; f < poll; ++f) run_frame(ctx, limit, first);
+    for (uint32_t f = 0; f < poll; ++f) run_frame(ctx, limit, first, true);
     frames += poll;
     if ((rc = fetch_counters(ctx)) != MIRT_OK) return rc;
     if (ctx->h_stats[S_FINISHED] - finished0 >= limit) break;

@@ -62,6 +62,36 @@ __device__ __forceinline__ void block_push2(BlockPush2 &sh, uint32_t *count0, ui
   __syncthreads();
 }
 
+// Block-aggregated reservation from a 64-bit counter: the lanes with `pred` get
+// consecutive numbers, the block's share taken with one atomic.  Must be
+// reached by every thread of the block; lanes without `pred` get ~0.
+struct BlockReserve {
+  uint32_t off[16];
+  unsigned long long base;
+};
+__device__ __forceinline__ unsigned long long block_reserve(BlockReserve &sh, unsigned long long *counter, bool pred) {
+  const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+  const uint32_t n_waves = (blockDim.x + 63u) >> 6;
+  const unsigned long long m = __ballot(pred);
+  if (lane == 0u) sh.off[wid] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (wid == 0u) {
+    const uint32_t w = lane & 15u;
+    const uint32_t c = (lane < 16u && w < n_waves) ? sh.off[w] : 0u;
+    uint32_t x = c;  // inclusive scan over the waves' counts
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, d, 16);
+      if (w >= (uint32_t)d) x += y;
+    }
+    if (lane == 15u) sh.base = x != 0u ? atomicAdd(counter, (unsigned long long)x) : 0ull;
+    if (lane < 16u && w < n_waves) sh.off[w] = x - c;
+  }
+  __syncthreads();
+  const unsigned long long r = pred ? sh.base + sh.off[wid] + rank_in_mask(m) : ~0ull;
+  __syncthreads();
+  return r;
+}
+
 // The same for a thread that pushes to at most one of N queues (`route` in
 // [0, N), or negative for none): one atomic per queue per block.
 template <int N>

@@ -37,6 +37,60 @@ __device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
   return (uint32_t)x;
 }
 
+// accumulateSample's sums (shaders/sample.slang:38-47) for one finished sample
+__device__ __forceinline__ void accumulate_sample(const DState &st, const DFrameParams &fp, uint32_t source, float4 rad) {
+  atomicAdd(&st.count[source], 1u);
+  atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(rad.x, fp.p.fixed_point_scale));
+  atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(rad.y, fp.p.fixed_point_scale));
+  atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(rad.z, fp.p.fixed_point_scale));
+}
+
+// camera basis (shaders/sample.slang:87-90)
+struct CamBasis {
+  v3 pos, up, right, top_left;
+  float dx, dy;
+};
+__device__ __forceinline__ CamBasis cam_basis(const MirtCamera &cam) {
+  CamBasis cb;
+  const v3 fwd = V3(cam.forward[0], cam.forward[1], cam.forward[2]);
+  cb.pos = V3(cam.position[0], cam.position[1], cam.position[2]);
+  cb.up = V3(cam.up[0], cam.up[1], cam.up[2]);
+  cb.right = cross3(fwd, cb.up);
+  cb.dx = cam.dims[0];
+  cb.dy = cam.dims[1];
+  cb.top_left = sub3(add3(scale3(fwd, cam.focal_length), scale3(cb.up, cb.dy)), scale3(cb.right, cb.dx));
+  return cb;
+}
+
+// spawnSample (shaders/sample.slang:59-102): sample number `si` of this render
+// call starts in `slot`.
+__device__ __forceinline__ void spawn_sample(const DState &st, const DFrameParams &fp, const CamBasis &cb, uint32_t slot,
+                                             unsigned long long si) {
+  uint32_t source, k;
+  if ((si >> 32) == 0ull) {
+    source = (uint32_t)si % st.n_sources;
+    k = (uint32_t)si / st.n_sources;
+  } else {
+    source = (uint32_t)(si % st.n_sources);
+    k = (uint32_t)(si / st.n_sources);
+  }
+  k += fp.first_sample;
+  const MirtSampleSource src = st.sources[source];
+  Rng rng = rng_init(fp.p.seed, source, k);
+  const float r1 = rng_next(rng);  // x jitter takes the first draw
+  const float r2 = rng_next(rng);
+  const float jx = r1 / (float)st.width, jy = r2 / (float)st.height;
+  const float sy = src.screen_pos[1] + jy, sx = src.screen_pos[0] + jx;
+  const v3 offset =
+      add3(scale3(scale3(scale3(cb.up, -2.0f), cb.dy), sy), scale3(scale3(scale3(cb.right, 2.0f), cb.dx), sx));
+  const v3 dir = normalize3(add3(cb.top_left, offset));
+  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+  p4[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(fp.p.max_bounces));
+  p4[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(source));
+  p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+  store_ray(st.ray, slot, cb.pos, dir, kNoPrim, kNoPrim);
+}
+
 __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   __shared__ unsigned long long sh_sample_base;
@@ -44,14 +98,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
   const uint32_t *term = st.qdata[Q_TERM0 + par];
   uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_TERM0 + par];
-  const MirtCamera &cam = fp.cam;
-
-  // camera basis (shaders/sample.slang:87-90)
-  const v3 fwd = V3(cam.forward[0], cam.forward[1], cam.forward[2]);
-  const v3 up = V3(cam.up[0], cam.up[1], cam.up[2]);
-  const v3 right = cross3(fwd, up);
-  const float dx = cam.dims[0], dy = cam.dims[1];
-  const v3 top_left = sub3(add3(scale3(fwd, cam.focal_length), scale3(up, dy)), scale3(right, dx));
+  const CamBasis cb = cam_basis(fp.cam);
 
   // The block reserves the sample numbers of all its entries with one atomic:
   // its grid-stride rounds cover full blocks of entries except the last one.
@@ -76,10 +123,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
       const float4 a = reinterpret_cast<const float4 *>(pp)[0];
       const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
       if (source != kNoSample) {
-        atomicAdd(&st.count[source], 1u);
-        atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(a.x, fp.p.fixed_point_scale));
-        atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(a.y, fp.p.fixed_point_scale));
-        atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(a.z, fp.p.fixed_point_scale));
+        accumulate_sample(st, fp, source, a);
         finished++;
       }
     }
@@ -88,28 +132,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
     next_sample += bs;
     const bool spawn = active && si < fp.sample_limit;
     if (spawn) {
-      uint32_t source, k;
-      if ((si >> 32) == 0ull) {
-        source = (uint32_t)si % st.n_sources;
-        k = (uint32_t)si / st.n_sources;
-      } else {
-        source = (uint32_t)(si % st.n_sources);
-        k = (uint32_t)(si / st.n_sources);
-      }
-      k += fp.first_sample;
-      const MirtSampleSource src = st.sources[source];
-      Rng rng = rng_init(fp.p.seed, source, k);
-      const float r1 = rng_next(rng);  // x jitter takes the first draw
-      const float r2 = rng_next(rng);
-      const float jx = r1 / (float)st.width, jy = r2 / (float)st.height;
-      const float sy = src.screen_pos[1] + jy, sx = src.screen_pos[0] + jx;
-      const v3 offset = add3(scale3(scale3(scale3(up, -2.0f), dy), sy), scale3(scale3(scale3(right, 2.0f), dx), sx));
-      const v3 dir = normalize3(add3(top_left, offset));
-      float4 *p4 = reinterpret_cast<float4 *>(pp);
-      p4[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(fp.p.max_bounces));
-      p4[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(source));
-      p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
-      store_ray(st.ray, slot, V3(cam.position[0], cam.position[1], cam.position[2]), dir, kNoPrim, kNoPrim);
+      spawn_sample(st, fp, cb, slot, si);
       spawned++;
     } else if (active) {
       reinterpret_cast<uint32_t *>(pp)[7] = kNoSample;  // the slot retires
@@ -357,7 +380,8 @@ __device__ __forceinline__ v3 material_brdf(v3 wi, v3 wo, v3 n, const DMaterial 
 // given in registers: emission, the three sampling draws, throughput update,
 // the bounce ray.  Returns whether the path goes on.
 __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &st, uint32_t slot, v3 wo, v3 hit_pos,
-                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim) {
+                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim, float4 &rad_out,
+                                                uint32_t &source_out) {
   float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
   float4 pa = p4[0], pb = p4[1];
   const float4 pr = p4[2];
@@ -382,6 +406,8 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &
   pb.z = pb.z * (brdf.z * ndotwi * 1.0f / pdf);
   const uint32_t bounces = __float_as_uint(pa.w) - 1u;
   pa.w = __uint_as_float(bounces);
+  rad_out = pa;
+  source_out = __float_as_uint(pb.w);
   p4[0] = pa;
   p4[1] = pb;
   p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
@@ -394,20 +420,35 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &
 // extensionMain's epilogue and shadeMain in one pass over the extension queue
 // (uber shading): the hit record stays in registers between the two, a miss
 // adds the sky and ends the path.
+//
+// RESPAWN: a path that ends here is accumulated and its slot takes the next
+// sample of the render call at once (accumulateSample + spawnSample of
+// shaders/sample.slang:35-102 done in place), so the slot is back on the
+// extension queue of the next frame without a trip through the terminate queue
+// and the sample kernel.  Streams are keyed per sample and the sums are
+// integers, so the accumulators end on the same bits as with the
+// three-kernel frame; only which frame a sample is credited in changes, which
+// is why mirt_step keeps the three-kernel frame.
 #ifndef MIRT_SHADE_WAVES
 #define MIRT_SHADE_WAVES 4
 #endif
+template <bool RESPAWN>
 __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
+  __shared__ BlockReserve shr;
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  unsigned long long shaded = 0;
+  CamBasis cb;
+  if (RESPAWN) cb = cam_basis(fp.cam);
+  unsigned long long shaded = 0, finished = 0, spawned = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
     bool alive = false;
+    float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // of a path that ends here
+    uint32_t source = kNoSample;
     if (active) {
       slot = ext[i];
       const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
@@ -426,22 +467,55 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
         a.x = a.x + b.x * sky;
         a.y = a.y + b.y * sky;
         a.z = a.z + b.z * sky;
-        p4[0] = a;
+        if (RESPAWN) {
+          rad = a;
+          source = __float_as_uint(b.w);
+        } else {
+          p4[0] = a;
+        }
       } else {
         best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
         v3 rpos, wo, hp, hn;
         uint32_t li, lp, ff;
         load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
         finish_hit(sc, wo, best, hp, hn, ff);
-        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim);
+        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim, rad, source);
         shaded++;
       }
     }
-    block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
-                &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+    if (RESPAWN) {
+      const bool done = active && !alive;
+      if (done) {
+        accumulate_sample(st, fp, source, rad);
+        finished++;
+      }
+      const unsigned long long si = block_reserve(shr, st.sample_index, done);
+      if (done && si < fp.sample_limit) {
+        spawn_sample(st, fp, cb, slot, si);
+        spawned++;
+        alive = true;
+      } else if (done) {
+        reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+      }
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
+                  false, slot);
+    } else {
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
+                  &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
-  if (lane_id() == 0u && shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
+  for (int off = 32; off > 0; off >>= 1) {
+    shaded += __shfl_down(shaded, off);
+    if (RESPAWN) {
+      finished += __shfl_down(finished, off);
+      spawned += __shfl_down(spawned, off);
+    }
+  }
+  if (lane_id() == 0u) {
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+  }
 }
 
 // ---------------------------------------------------------- accumulator add
@@ -583,7 +657,8 @@ void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_finish_shade_uber, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  if (fp.respawn) hipLaunchKernelGGL((k_finish_shade_uber<true>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_finish_shade_uber<false>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n) {
