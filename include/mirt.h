@@ -336,6 +336,22 @@ int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax,
 int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                              uint32_t repeats, double *ms_per_launch);
 
+/* ------------------------------------------------------------- BLAS build */
+
+/* BLAS::new (src/blas.rs:62-78) with BVH::initialize(4) (src/bvh.rs:52-178) on
+ * the device, for the caller that builds a mesh's BLAS at load time
+ * (MeshServer, src/mesh.rs:118-145, on a rayon worker in the reference).
+ * positions4: n_positions x 4 floats (Mesh::positions); faces4: n_faces x 4
+ * indices (Mesh::faces, w = 0), reordered IN PLACE exactly as the reference's
+ * partition loop reorders mesh.faces; nodes: room for nodes_capacity records
+ * (2 * n_faces always suffices), filled in BVHNodeGPU form with the
+ * reference's node numbering and skip links; *n_nodes = nodes written (or
+ * needed, when nodes_capacity is too small).  device_ms (may be NULL) gets the
+ * time of the build on the device without the copies.  Synchronises. */
+int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions,
+                    uint32_t *faces4, uint32_t n_faces, MirtBVHNode *nodes,
+                    uint32_t nodes_capacity, uint32_t *n_nodes, float *device_ms);
+
 /* ------------------------------------------------- several GPUs, one process */
 
 /* A group is one context per device ordinal, driven from one host thread of

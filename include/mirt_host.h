@@ -38,6 +38,27 @@ int mirth_load_mesh_model_file(mirth_scene *s, const char *path);
 /* Procedural dragon-class mesh: 2*n_u*n_v triangles. */
 int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed);
 
+/* The BLAS of every mesh loaded AFTER this call is built by `fn` instead of the
+ * host builder (NULL restores the host builder).  `fn` has the signature of
+ * mirt_build_blas with a user pointer in place of the context, so a caller
+ * that links both libraries can build on the device:
+ *   int on_device(void *ctx, const float *p, uint32_t np, uint32_t *f, uint32_t nf,
+ *                 MirtBVHNode *nodes, uint32_t cap, uint32_t *n)
+ *   { return mirt_build_blas((mirt_ctx *)ctx, p, np, f, nf, nodes, cap, n, NULL); }
+ * It must reorder faces4 in place and fill `nodes` exactly as BLAS::new does
+ * (src/blas.rs:62-78) and return 0; any other value fails the load. */
+typedef int (*mirth_blas_builder_fn)(void *user, const float *positions4, uint32_t n_positions,
+                                     uint32_t *faces4, uint32_t n_faces, MirtBVHNode *nodes,
+                                     uint32_t nodes_capacity, uint32_t *n_nodes);
+int mirth_set_blas_builder(mirth_scene *s, mirth_blas_builder_fn fn, void *user);
+/* The host builder on its own, on positions taken as they are (no
+ * Mesh::from_model normalisation): BLAS::new (src/blas.rs:62-78).  Same
+ * contract as the callback above; *n_nodes holds the count needed when
+ * nodes_capacity is too small (the call then returns -1). */
+int mirth_build_blas_host(const float *positions4, uint32_t n_positions, uint32_t *faces4,
+                          uint32_t n_faces, MirtBVHNode *nodes, uint32_t nodes_capacity,
+                          uint32_t *n_nodes);
+
 /* MaterialServer::add_material (src/material.rs:54-57) */
 int mirth_add_material(mirth_scene *s, const MirtMaterial *m);
 void mirth_default_material(MirtMaterial *out); /* src/material.rs:27-42 */

@@ -1176,6 +1176,30 @@ void group_free_staging(mirt_group *g) {
 
 extern "C" {
 
+int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions, uint32_t *faces4, uint32_t n_faces,
+                    MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes, float *device_ms) {
+  ENTER(ctx);
+  if (!n_nodes || !nodes || nodes_capacity == 0 || (n_faces != 0 && (!faces4 || !positions4)))
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_blas: null argument");
+  if (n_faces > (1u << 30)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_blas: too many faces");
+  if (device_ms) *device_ms = 0.0f;
+  if (n_faces == 0) {
+    // BLAS::new keeps the empty root leaf (src/blas.rs:64-71)
+    memset(&nodes[0], 0, sizeof(MirtBVHNode));
+    nodes[0].is_leaf = 1u;
+    *n_nodes = 1;
+    return MIRT_OK;
+  }
+  // the centroid also reads positions[face.w]
+  for (size_t k = 0; k < (size_t)n_faces * 4; ++k)
+    if (faces4[k] >= n_positions) return fail(ctx, MIRT_ERR_BAD_SCENE, "build_blas: face index out of range");
+  std::string err;
+  const int rc = build_blas_device(ctx->stream, positions4, n_positions, faces4, n_faces, nodes, nodes_capacity, n_nodes,
+                                   device_ms, err);
+  if (rc != MIRT_OK) return fail(ctx, rc, err);
+  return MIRT_OK;
+}
+
 int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group) {
   if (!device_ordinals || n < 1 || !out_group) return MIRT_ERR_INVALID_ARGUMENT;
   *out_group = nullptr;

@@ -1,0 +1,549 @@
+// build.hip — the BLAS builder on the device: BLAS::new + BVH::initialize
+// (src/blas.rs:18-78, src/bvh.rs:52-178) for gfx950.
+//
+// The reference builds a BLAS on a host thread with a recursive median split
+// whose partition loop is sequential (src/bvh.rs:105-112):
+//     while i < j { if centroid(i)[axis] < split { i += 1 } else { swap(i, j); j -= 1 } }
+// Triangle ids are positions in the order this loop leaves behind and node ids
+// follow the recursion, so a device builder has to reproduce both exactly.
+//
+// The loop in closed form.  Call an element L when its centroid is below the
+// split and R otherwise; let F be the range read from its front and B the range
+// read from its back.  The loop tests a run of F that ends with its first R,
+// then a run of B that ends with its first L, and so on, until n - 1 elements
+// have been tested; the one element left over is never tested.  With
+//   FR(m) = front index of the m-th R of F,  BL(m) = back index of the m-th L of B,
+// an element at front index p (back index k = n - 1 - p) is
+//   tested as part of F  iff  p + (BL(m-1) + 1) < n - 1,  m - 1 = number of R before p,
+//   tested as part of B  iff  k + FR(m) + 1    < n - 1,  m - 1 = number of L behind p,
+// and ends at position
+//   F, L: p          F, R (the m-th): n - 2 - BL(m-1)
+//   B, R: p - 1      B, L (the m-th): FR(m)
+//   untested: i = number of tested L  (the split point; it always lands right).
+// Two prefix counts and two scatter tables give every element its place, so a
+// node of any size is partitioned by one thread block with scans.
+//
+// The tree is grown level by level (one block per node, two block shapes by node
+// size).  Nodes get temporary ids in creation order; the reference's ids — the
+// two children pushed side by side, then the whole left subtree, then the right
+// one — and the skip links (src/bvh.rs:159-172) follow from subtree sizes in a
+// bottom-up and a top-down sweep over the levels.
+//
+// min / max keep the first operand on ties like the host model's (host.hpp
+// fmin2 / fmax2), which decides the sign of a zero bound: reductions carry the
+// position with the value so that the first occurrence wins.
+#include <float.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mirt {
+
+namespace {
+
+struct TNode {
+  float lb[3], ub[3];
+  uint32_t s, e;      // element range
+  uint32_t child;     // temporary id of the left child (right = child + 1), 0 = leaf
+  uint32_t desc;      // number of proper descendants
+  uint32_t idx;       // id in the reference's numbering
+  uint32_t base;      // id the first child gets
+  uint32_t skip;      // skip link (reference numbering)
+  uint32_t pad[3];
+};
+static_assert(sizeof(TNode) == 64, "TNode is one 64-byte record");
+
+struct BuildBufs {
+  const float4 *pos;
+  const uint4 *faces;
+  uint4 *faces_out;
+  float4 *cen, *bmn, *bmx;  // per face id: centroid, box
+  uint32_t *perm, *perm2;   // face id at every position
+  uint32_t *rl, *lr;        // per position: R count before (bit 31: the element is R); L count behind
+  uint32_t *pos_r, *pos_lb; // m-th R from the front -> front index; m-th L from the back -> back index
+  TNode *tn;
+  uint32_t *n_tmp;          // [0] nodes created so far, [1] how many of them got kBigNode elements or more
+  uint32_t nf;
+};
+
+constexpr uint32_t kLeafMax = 4u;      // BLAS::new: initialize(4)
+constexpr uint32_t kBigNode = 2048u;   // nodes this big get a 1024-thread block
+
+__device__ __forceinline__ float hmin2(float a, float b) { return b < a ? b : a; }  // first operand on ties
+__device__ __forceinline__ float hmax2(float a, float b) { return b > a ? b : a; }
+
+__device__ __forceinline__ uint32_t b_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t b_rank(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// order-preserving key of a float with both zeros equal
+__device__ __forceinline__ uint32_t ord_key(float v) {
+  const uint32_t k = __float_as_uint(v + 0.0f);
+  return (k & 0x80000000u) ? ~k : (k | 0x80000000u);
+}
+
+template <int NT>
+struct BlockTmp {
+  uint32_t w[16];
+  unsigned long long k[16];
+  float f[16];
+};
+
+// exclusive count of `flag` over the block in thread order; `total` for everyone
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_count(BlockTmp<NT> &sh, bool flag, uint32_t &total) {
+  const unsigned long long m = __ballot(flag);
+  const uint32_t rank = b_rank(m);
+  if (NT == 64) {
+    total = (uint32_t)__popcll(m);
+    return rank;
+  }
+  const uint32_t wid = threadIdx.x >> 6;
+  if (b_lane() == 0u) sh.w[wid] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t pre = 0u, tot = 0u;
+#pragma unroll
+  for (uint32_t w = 0; w < NT / 64; ++w) {
+    const uint32_t c = sh.w[w];
+    pre += w < wid ? c : 0u;
+    tot += c;
+  }
+  __syncthreads();
+  total = tot;
+  return pre + rank;
+}
+
+template <int NT>
+__device__ __forceinline__ uint32_t block_sum(BlockTmp<NT> &sh, uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off);
+  if (NT == 64) return v;
+  const uint32_t wid = threadIdx.x >> 6;
+  if (b_lane() == 0u) sh.w[wid] = v;
+  __syncthreads();
+  uint32_t tot = 0u;
+#pragma unroll
+  for (uint32_t w = 0; w < NT / 64; ++w) tot += sh.w[w];
+  __syncthreads();
+  return tot;
+}
+
+template <int NT, bool MAX>
+__device__ __forceinline__ float block_minmax(BlockTmp<NT> &sh, float v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = MAX ? (o > v ? o : v) : (o < v ? o : v);
+  }
+  if (NT == 64) return v;
+  const uint32_t wid = threadIdx.x >> 6;
+  if (b_lane() == 0u) sh.f[wid] = v;
+  __syncthreads();
+  float r = sh.f[0];
+#pragma unroll
+  for (uint32_t w = 1; w < NT / 64; ++w) {
+    const float o = sh.f[w];
+    r = MAX ? (o > r ? o : r) : (o < r ? o : r);
+  }
+  __syncthreads();
+  return r;
+}
+
+template <int NT>
+__device__ __forceinline__ unsigned long long block_min_key(BlockTmp<NT> &sh, unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  if (NT == 64) return v;
+  const uint32_t wid = threadIdx.x >> 6;
+  if (b_lane() == 0u) sh.k[wid] = v;
+  __syncthreads();
+  unsigned long long r = sh.k[0];
+#pragma unroll
+  for (uint32_t w = 1; w < NT / 64; ++w) {
+    const unsigned long long o = sh.k[w];
+    r = o < r ? o : r;
+  }
+  __syncthreads();
+  return r;
+}
+
+// The box of positions [a, b) of the element order (compute_node_bounds of a
+// leaf, src/bvh.rs:58-63): per axis the smallest / largest value, and among
+// equal values the first in order — what the sequential fold keeps.
+template <int NT>
+__device__ __forceinline__ void range_bounds(BlockTmp<NT> &sh, const BuildBufs &bb, uint32_t a, uint32_t b, float lb[3],
+                                             float ub[3]) {
+  unsigned long long kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {~0ull, ~0ull, ~0ull};
+  for (uint32_t p = a + threadIdx.x; p < b; p += NT) {
+    const uint32_t f = bb.perm[p];
+    const float4 mn = bb.bmn[f], mx = bb.bmx[f];
+    const float vmn[3] = {mn.x, mn.y, mn.z}, vmx[3] = {mx.x, mx.y, mx.z};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const unsigned long long k0 = ((unsigned long long)ord_key(vmn[ax]) << 32) | (p - a);
+      const unsigned long long k1 = ((unsigned long long)(~ord_key(vmx[ax])) << 32) | (p - a);
+      kmin[ax] = k0 < kmin[ax] ? k0 : kmin[ax];
+      kmax[ax] = k1 < kmax[ax] ? k1 : kmax[ax];
+    }
+  }
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const uint32_t pmin = (uint32_t)block_min_key<NT>(sh, kmin[ax]);
+    const uint32_t pmax = (uint32_t)block_min_key<NT>(sh, kmax[ax]);
+    const float4 mn = bb.bmn[bb.perm[a + pmin]], mx = bb.bmx[bb.perm[a + pmax]];
+    lb[ax] = ax == 0 ? mn.x : (ax == 1 ? mn.y : mn.z);
+    ub[ax] = ax == 0 ? mx.x : (ax == 1 ? mx.y : mx.z);
+  }
+}
+
+// elem_bounds / elem_centroid of every face (src/blas.rs:19-37) and the
+// identity order.  The centroid sums FOUR positions — the face's three and
+// positions[face.w = 0] — and divides by three.
+__global__ __launch_bounds__(256) void k_build_prep(BuildBufs bb) {
+  const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+  if (f >= bb.nf) return;
+  const uint4 face = bb.faces[f];
+  const float4 p0 = bb.pos[face.x], p1 = bb.pos[face.y], p2 = bb.pos[face.z], p3 = bb.pos[face.w];
+  bb.bmn[f] = make_float4(hmin2(hmin2(p0.x, p1.x), p2.x), hmin2(hmin2(p0.y, p1.y), p2.y), hmin2(hmin2(p0.z, p1.z), p2.z), 0.0f);
+  bb.bmx[f] = make_float4(hmax2(hmax2(p0.x, p1.x), p2.x), hmax2(hmax2(p0.y, p1.y), p2.y), hmax2(hmax2(p0.z, p1.z), p2.z), 0.0f);
+  bb.cen[f] = make_float4((((p0.x + p1.x) + p2.x) + p3.x) / 3.0f, (((p0.y + p1.y) + p2.y) + p3.y) / 3.0f,
+                          (((p0.z + p1.z) + p2.z) + p3.z) / 3.0f, 0.0f);
+  bb.perm[f] = f;
+}
+
+// the root: a leaf over every face (src/blas.rs:64-71) with its box
+__global__ __launch_bounds__(1024) void k_build_root(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  float lb[3], ub[3];
+  range_bounds<1024>(sh, bb, 0u, bb.nf, lb, ub);
+  if (threadIdx.x == 0u) {
+    TNode n{};
+    for (int ax = 0; ax < 3; ++ax) {
+      n.lb[ax] = lb[ax];
+      n.ub[ax] = ub[ax];
+    }
+    n.s = 0u;
+    n.e = bb.nf;
+    bb.tn[0] = n;
+    bb.n_tmp[0] = 1u;
+    bb.n_tmp[1] = bb.nf >= kBigNode ? 1u : 0u;
+  }
+}
+
+// subdivide (src/bvh.rs:68-157) for the nodes [first, first + gridDim.x) of one
+// level, one block per node; the block shape takes the nodes of its size class.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first) {
+  __shared__ BlockTmp<NT> sh;
+  __shared__ uint32_t sh_unt;
+  const uint32_t id = first + blockIdx.x;
+  const TNode node = bb.tn[id];
+  const uint32_t s = node.s, n = node.e - node.s;
+  if (n <= kLeafMax) return;
+  if ((NT == 1024) != (n >= kBigNode)) return;
+  const uint32_t tid = threadIdx.x;
+
+  // the longest axis of the node's box (src/bvh.rs:81-88)
+  const float ex = node.ub[0] - node.lb[0], ey = node.ub[1] - node.lb[1], ez = node.ub[2] - node.lb[2];
+  int axis = 0;
+  if (ey > ex) axis = 1;
+  if (ez > (axis == 0 ? ex : ey)) axis = 2;
+  auto centroid = [&](uint32_t p) {
+    const float4 c = bb.cen[bb.perm[s + p]];
+    return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+  };
+
+  // split = midpoint of the centroids' range on that axis (src/bvh.rs:94-103)
+  float cmin = FLT_MAX, cmax = -FLT_MAX;
+  for (uint32_t p = tid; p < n; p += NT) {
+    const float c = centroid(p);
+    cmin = c < cmin ? c : cmin;
+    cmax = c > cmax ? c : cmax;
+  }
+  cmin = block_minmax<NT, false>(sh, cmin);
+  cmax = block_minmax<NT, true>(sh, cmax);
+  const float split = (cmin + cmax) * 0.5f;
+
+  // from the front: R count before every element, table of the R's
+  uint32_t n_r = 0u;
+  for (uint32_t base = 0; base < n; base += NT) {
+    const uint32_t p = base + tid;
+    const bool is_r = p < n && !(centroid(p) < split);
+    uint32_t tot;
+    const uint32_t ex_r = n_r + block_excl_count<NT>(sh, is_r, tot);
+    if (p < n) bb.rl[s + p] = ex_r | (is_r ? 0x80000000u : 0u);
+    if (is_r) bb.pos_r[s + ex_r] = p;
+    n_r += tot;
+  }
+  __syncthreads();
+  // from the back: L count behind every element, table of the L's
+  uint32_t n_l = 0u;
+  for (uint32_t base = 0; base < n; base += NT) {
+    const uint32_t k = base + tid;
+    const bool is_l = k < n && (bb.rl[s + n - 1u - k] & 0x80000000u) == 0u;
+    uint32_t tot;
+    const uint32_t ex_l = n_l + block_excl_count<NT>(sh, is_l, tot);
+    if (k < n) bb.lr[s + n - 1u - k] = ex_l;
+    if (is_l) bb.pos_lb[s + ex_l] = k;
+    n_l += tot;
+  }
+  __syncthreads();
+
+  // every tested element to its place; count the tested L's
+  const unsigned long long kInf = 1ull << 40;
+  uint32_t my_l = 0u;
+  if (tid == 0u) sh_unt = 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t p = tid; p < n; p += NT) {
+    const uint32_t w = bb.rl[s + p];
+    const bool is_r = (w & 0x80000000u) != 0u;
+    const uint32_t m1 = w & 0x7FFFFFFFu;  // R's before p
+    const unsigned long long prev_b = m1 == 0u ? 0ull : (m1 - 1u < n_l ? (unsigned long long)bb.pos_lb[s + m1 - 1u] + 1ull : kInf);
+    const uint32_t k = n - 1u - p, ml = bb.lr[s + p];  // L's behind p
+    const unsigned long long fr = ml < n_r ? (unsigned long long)bb.pos_r[s + ml] : kInf;
+    const bool t_f = (unsigned long long)p + prev_b < (unsigned long long)(n - 1u);
+    const bool t_b = (unsigned long long)k + fr + 1ull < (unsigned long long)(n - 1u);
+    const uint32_t f = bb.perm[s + p];
+    if (t_f) {
+      const uint32_t d = is_r ? n - 1u - (uint32_t)prev_b : p;
+      bb.perm2[s + d] = f;
+      my_l += is_r ? 0u : 1u;
+    } else if (t_b) {
+      const uint32_t d = is_r ? p - 1u : (uint32_t)fr;
+      bb.perm2[s + d] = f;
+      my_l += is_r ? 0u : 1u;
+    } else {
+      sh_unt = f;  // exactly one element is never tested
+    }
+  }
+  const uint32_t i = block_sum<NT>(sh, my_l);  // the split point, relative to s
+  __syncthreads();
+  if (tid == 0u) bb.perm2[s + i] = sh_unt;
+  __syncthreads();
+  // the swaps happen whether or not the node ends up split
+  for (uint32_t p = tid; p < n; p += NT) bb.perm[s + p] = bb.perm2[s + p];
+  __syncthreads();
+  if (i == 0u) return;  // one-sided: the node stays a leaf (src/bvh.rs:114-119; i == n cannot happen)
+
+  float llb[3], lub[3], rlb[3], rub[3];
+  range_bounds<NT>(sh, bb, s, s + i, llb, lub);
+  range_bounds<NT>(sh, bb, s + i, s + n, rlb, rub);
+  if (tid == 0u) {
+    const uint32_t c = atomicAdd(&bb.n_tmp[0], 2u);
+    const uint32_t big = (i >= kBigNode ? 1u : 0u) + (n - i >= kBigNode ? 1u : 0u);
+    if (big != 0u) atomicAdd(&bb.n_tmp[1], big);
+    TNode l{}, r{};
+    for (int ax = 0; ax < 3; ++ax) {
+      l.lb[ax] = llb[ax];
+      l.ub[ax] = lub[ax];
+      r.lb[ax] = rlb[ax];
+      r.ub[ax] = rub[ax];
+    }
+    l.s = s;
+    l.e = s + i;
+    r.s = s + i;
+    r.e = s + n;
+    bb.tn[c] = l;
+    bb.tn[c + 1u] = r;
+    bb.tn[id].child = c;
+  }
+}
+
+// Bottom-up over one level: subtree sizes, and the box of an inner node as the
+// union of its children's final boxes (src/bvh.rs:54-57,156).
+__global__ __launch_bounds__(256) void k_build_up(BuildBufs bb, uint32_t first, uint32_t count) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= count) return;
+  TNode n = bb.tn[first + t];
+  if (n.child == 0u) {
+    n.desc = 0u;
+  } else {
+    const TNode l = bb.tn[n.child], r = bb.tn[n.child + 1u];
+    for (int ax = 0; ax < 3; ++ax) {
+      n.lb[ax] = hmin2(l.lb[ax], r.lb[ax]);
+      n.ub[ax] = hmax2(l.ub[ax], r.ub[ax]);
+    }
+    n.desc = 2u + l.desc + r.desc;
+  }
+  bb.tn[first + t] = n;
+}
+
+// Top-down over one level: the reference's node ids (children side by side,
+// then the left subtree, then the right one: src/bvh.rs:136-142) and skip links
+// (left -> right, right -> the parent's: src/bvh.rs:159-172); writes the node
+// in BVHNodeGPU form (src/bvh.rs:200-224).
+__global__ __launch_bounds__(256) void k_build_down(BuildBufs bb, uint32_t first, uint32_t count, MirtBVHNode *out) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t id = first + t;
+  TNode n = bb.tn[id];
+  if (id == 0u) {
+    n.idx = 0u;
+    n.base = 1u;
+    n.skip = 0u;
+  }
+  uint32_t left = 0u;
+  if (n.child != 0u) {
+    TNode *l = &bb.tn[n.child], *r = &bb.tn[n.child + 1u];
+    left = n.base;
+    l->idx = n.base;
+    r->idx = n.base + 1u;
+    l->base = n.base + 2u;
+    r->base = n.base + 2u + l->desc;
+    l->skip = n.base + 1u;
+    r->skip = n.skip;
+  }
+  MirtBVHNode g;
+  g.lb[0] = n.lb[0]; g.lb[1] = n.lb[1]; g.lb[2] = n.lb[2]; g.lb[3] = 0.0f;
+  g.ub[0] = n.ub[0]; g.ub[1] = n.ub[1]; g.ub[2] = n.ub[2]; g.ub[3] = 0.0f;
+  g.left = left;
+  g.right = n.skip;
+  g.is_leaf = n.child == 0u ? 1u : 0u;
+  g.start = n.s;
+  g.end = n.e;
+  g.pad[0] = g.pad[1] = g.pad[2] = 0u;
+  out[n.idx] = g;
+}
+
+// mesh.faces in the order the build left them in (elem_swap, src/blas.rs:39-41)
+__global__ __launch_bounds__(256) void k_build_faces(BuildBufs bb) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p < bb.nf) bb.faces_out[p] = bb.faces[bb.perm[p]];
+}
+
+struct DevMem {
+  std::vector<void *> ptrs;
+  ~DevMem() {
+    for (void *p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t get(T **out, size_t count) {
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(p);
+    *out = reinterpret_cast<T *>(p);
+    return e;
+  }
+};
+
+}  // namespace
+
+#define BUILD_TRY(expr)                                              \
+  do {                                                               \
+    const hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) {                                          \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);       \
+      return _e == hipErrorOutOfMemory ? MIRT_ERR_OUT_OF_MEMORY : MIRT_ERR_HIP; \
+    }                                                                \
+  } while (0)
+
+int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
+                      uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
+                      float *device_ms, std::string &err) {
+  DevMem mem;
+  BuildBufs bb{};
+  bb.nf = n_faces;
+  float4 *d_pos = nullptr;
+  uint4 *d_faces = nullptr;
+  MirtBVHNode *d_out = nullptr;
+  const size_t cap = 2 * (size_t)n_faces;  // a split adds two nodes and there are fewer than n_faces splits
+  BUILD_TRY(mem.get(&d_pos, n_positions));
+  BUILD_TRY(mem.get(&d_faces, n_faces));
+  BUILD_TRY(mem.get(&bb.faces_out, n_faces));
+  BUILD_TRY(mem.get(&bb.cen, n_faces));
+  BUILD_TRY(mem.get(&bb.bmn, n_faces));
+  BUILD_TRY(mem.get(&bb.bmx, n_faces));
+  BUILD_TRY(mem.get(&bb.perm, n_faces));
+  BUILD_TRY(mem.get(&bb.perm2, n_faces));
+  BUILD_TRY(mem.get(&bb.rl, n_faces));
+  BUILD_TRY(mem.get(&bb.lr, n_faces));
+  BUILD_TRY(mem.get(&bb.pos_r, n_faces));
+  BUILD_TRY(mem.get(&bb.pos_lb, n_faces));
+  BUILD_TRY(mem.get(&bb.tn, cap));
+  BUILD_TRY(mem.get(&bb.n_tmp, 2));
+  BUILD_TRY(mem.get(&d_out, cap));
+  bb.pos = d_pos;
+  bb.faces = d_faces;
+  BUILD_TRY(hipMemcpyAsync(d_pos, positions4, (size_t)n_positions * 16, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemcpyAsync(d_faces, faces4, (size_t)n_faces * 16, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemsetAsync(bb.tn, 0, cap * sizeof(TNode), stream));
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  BUILD_TRY(hipEventCreate(&ev0));
+  BUILD_TRY(hipEventCreate(&ev1));
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+  } guard{ev0, ev1};
+  BUILD_TRY(hipEventRecord(ev0, stream));
+
+  const unsigned fblocks = (n_faces + 255u) / 256u;
+  hipLaunchKernelGGL(k_build_prep, dim3(fblocks), dim3(256), 0, stream, bb);
+  hipLaunchKernelGGL(k_build_root, dim3(1), dim3(1024), 0, stream, bb);
+
+  // grow the tree one level at a time; a level is the run of nodes the previous one created
+  std::vector<std::pair<uint32_t, uint32_t>> levels;  // first id, count
+  uint32_t big_now = 0;
+  uint32_t first = 0, count = 1, big_seen = 0;
+  while (count != 0u) {
+    levels.push_back({first, count});
+    uint32_t tot[2] = {0, 0};
+    if (levels.size() == 1) {
+      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 8, hipMemcpyDeviceToHost, stream));
+      BUILD_TRY(hipStreamSynchronize(stream));
+    } else {
+      tot[1] = big_now;
+    }
+    // the 1024-thread shape only when this level holds a node of its size class
+    if (tot[1] != big_seen) hipLaunchKernelGGL((k_build_split<1024>), dim3(count), dim3(1024), 0, stream, bb, first);
+    big_seen = tot[1];
+    hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
+    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 8, hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipStreamSynchronize(stream));
+    const uint32_t total = tot[0];
+    big_now = tot[1];
+    if (total > cap || total < first + count) {
+      err = "build_blas: node count out of range";
+      return MIRT_ERR_HIP;
+    }
+    first += count;
+    count = total - first;
+    if (levels.size() > (size_t)n_faces + 2) {
+      err = "build_blas: the tree is deeper than it can be";
+      return MIRT_ERR_HIP;
+    }
+  }
+  const uint32_t total = first;
+  for (size_t l = levels.size(); l-- > 0;)
+    hipLaunchKernelGGL(k_build_up, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second);
+  for (size_t l = 0; l < levels.size(); ++l)
+    hipLaunchKernelGGL(k_build_down, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second, d_out);
+  hipLaunchKernelGGL(k_build_faces, dim3(fblocks), dim3(256), 0, stream, bb);
+  BUILD_TRY(hipEventRecord(ev1, stream));
+  BUILD_TRY(hipGetLastError());
+
+  if (total > nodes_capacity) {
+    BUILD_TRY(hipStreamSynchronize(stream));
+    *n_nodes = total;
+    err = "build_blas: nodes_capacity is too small (n_nodes holds the count needed)";
+    return MIRT_ERR_INVALID_ARGUMENT;
+  }
+  BUILD_TRY(hipMemcpyAsync(nodes_out, d_out, (size_t)total * sizeof(MirtBVHNode), hipMemcpyDeviceToHost, stream));
+  BUILD_TRY(hipMemcpyAsync(faces4, bb.faces_out, (size_t)n_faces * 16, hipMemcpyDeviceToHost, stream));
+  BUILD_TRY(hipStreamSynchronize(stream));
+  *n_nodes = total;
+  if (device_ms) {
+    float ms = 0.0f;
+    BUILD_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    *device_ms = ms;
+  }
+  return MIRT_OK;
+}
+
+}  // namespace mirt

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "layout.h"
 #include "mirt.h"
 
@@ -87,5 +89,12 @@ void launch_init_slots(const LaunchCfg &cfg, const DState &st);
 void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,
                   MirtHitId *out, unsigned long long *counts5, uint32_t *work, bool any_hit, bool counting);
 void launch_math_selftest(hipStream_t stream, const float *a, const float *b, const float *c, size_t n, float *out6);
+
+// BLAS::new on the device (build.hip): host arrays in, `faces4` reordered in
+// place, nodes in BVHNodeGPU form out.  Face indices must have been checked
+// against n_positions.  Returns a MirtStatus and a message in `err`.
+int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
+                      uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
+                      float *device_ms, std::string &err);
 
 }  // namespace mirt

@@ -20,6 +20,13 @@ namespace {
 
 const char kMagic[8] = {'M', 'I', 'R', 'T', 'M', 'E', 'S', 'H'};
 
+// the id add_mesh returned, or -1 with the message of a failed builder callback
+int added(mirth_scene *s, uint32_t id) {
+  if (id != 0xFFFFFFFFu) return (int)id;
+  s->error = s->scene.build_error;
+  return -1;
+}
+
 bool write_model_file(const std::string &path, const ObjModel &m, std::string &err) {
   FILE *f = fopen(path.c_str(), "wb");
   if (!f) {
@@ -130,11 +137,11 @@ int mirth_load_mesh_obj(mirth_scene *s, const char *path) {
   if (it != s->scene.by_desc.end()) return (int)it->second;
   ObjModel m;
   if (!load_obj_first_model(path, m, s->error)) return -1;
-  return (int)s->scene.add_mesh(key, Mesh::from_model(m));
+  return added(s, s->scene.add_mesh(key, Mesh::from_model(m)));
 }
 
-int mirth_load_mesh_rect(mirth_scene *s) { return s ? (int)s->scene.add_mesh("Rect", Mesh::rect()) : -1; }
-int mirth_load_mesh_cube(mirth_scene *s) { return s ? (int)s->scene.add_mesh("Cube", Mesh::cube()) : -1; }
+int mirth_load_mesh_rect(mirth_scene *s) { return s ? added(s, s->scene.add_mesh("Rect", Mesh::rect())) : -1; }
+int mirth_load_mesh_cube(mirth_scene *s) { return s ? added(s, s->scene.add_mesh("Cube", Mesh::cube())) : -1; }
 
 int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positions, uint32_t n_positions,
                           const float *normals, uint32_t n_normals, const uint32_t *indices,
@@ -145,7 +152,7 @@ int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positio
   if (normals) m.normals.assign(normals, normals + n_normals);
   m.indices.assign(indices, indices + n_indices);
   if (!validate_model(m, s->error)) return -1;
-  return (int)s->scene.add_mesh(std::string("MODEL:") + name, Mesh::from_model(m));
+  return added(s, s->scene.add_mesh(std::string("MODEL:") + name, Mesh::from_model(m)));
 }
 
 int mirth_load_mesh_model_file(mirth_scene *s, const char *path) {
@@ -155,7 +162,7 @@ int mirth_load_mesh_model_file(mirth_scene *s, const char *path) {
   if (it != s->scene.by_desc.end()) return (int)it->second;
   ObjModel m;
   if (!read_model_file(path, m, s->error) || !validate_model(m, s->error)) return -1;
-  return (int)s->scene.add_mesh(key, Mesh::from_model(m));
+  return added(s, s->scene.add_mesh(key, Mesh::from_model(m)));
 }
 
 int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed) {
@@ -163,7 +170,7 @@ int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t se
   std::string key = "KNOT:" + std::to_string(n_u) + "x" + std::to_string(n_v) + ":" + std::to_string(seed);
   auto it = s->scene.by_desc.find(key);
   if (it != s->scene.by_desc.end()) return (int)it->second;
-  return (int)s->scene.add_mesh(key, Mesh::from_model(make_knot_model(n_u, n_v, seed)));
+  return added(s, s->scene.add_mesh(key, Mesh::from_model(make_knot_model(n_u, n_v, seed))));
 }
 
 int mirth_add_material(mirth_scene *s, const MirtMaterial *m) {
@@ -191,6 +198,35 @@ int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3],
   if (!s || !dims || !pos) return -1;
   s->bound = false;
   spawn_cornell(s->scene, {dims[0], dims[1], dims[2]}, {pos[0], pos[1], pos[2]}, with_ceiling_light != 0);
+  if (!s->scene.build_error.empty()) {
+    s->error = s->scene.build_error;
+    return -1;
+  }
+  return 0;
+}
+
+int mirth_build_blas_host(const float *positions4, uint32_t n_positions, uint32_t *faces4, uint32_t n_faces,
+                          MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes) {
+  if (!n_nodes || !nodes || (n_faces != 0 && (!positions4 || !faces4))) return -1;
+  for (size_t k = 0; k < (size_t)n_faces * 4; ++k)
+    if (faces4[k] >= n_positions) return -1;
+  Mesh m;
+  m.positions.resize(n_positions);
+  for (size_t i = 0; i < n_positions; ++i)
+    m.positions[i] = {positions4[4 * i], positions4[4 * i + 1], positions4[4 * i + 2], positions4[4 * i + 3]};
+  m.faces.assign(faces4, faces4 + (size_t)n_faces * 4);
+  BLAS blas(std::move(m));
+  *n_nodes = (uint32_t)blas.nodes.size();
+  if (blas.nodes.size() > nodes_capacity) return -1;
+  for (size_t i = 0; i < blas.nodes.size(); ++i) nodes[i] = to_gpu(blas.nodes[i]);
+  if (n_faces) memcpy(faces4, blas.mesh.faces.data(), (size_t)n_faces * 16);
+  return 0;
+}
+
+int mirth_set_blas_builder(mirth_scene *s, mirth_blas_builder_fn fn, void *user) {
+  if (!s) return -1;
+  s->scene.blas_builder = fn;
+  s->scene.blas_builder_user = user;
   return 0;
 }
 
@@ -327,6 +363,10 @@ int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32
       info->width = 1920; info->height = 1080; info->spp = 64; info->max_bounces = 8;
       break;
     }
+  }
+  if (!sc.build_error.empty()) {
+    s->error = sc.build_error;
+    return -1;
   }
   return 0;
 }

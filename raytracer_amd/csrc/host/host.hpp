@@ -120,7 +120,16 @@ struct Entity {
 
 // MeshServer (src/mesh.rs:70-285) + MaterialServer (src/material.rs:47-71) +
 // the entity list + the packing rules of binder_system (src/binder.rs:198-282).
+// A BLAS builder supplied by the caller (the signature of mirt_build_blas
+// without its context): reorders faces4 in place, fills `nodes`, returns 0 on
+// success.  When set, add_mesh uses it instead of the host builder.
+typedef int (*BlasBuilderFn)(void *user, const float *positions4, uint32_t n_positions, uint32_t *faces4,
+                             uint32_t n_faces, MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes);
+
 struct Scene {
+  BlasBuilderFn blas_builder = nullptr;
+  void *blas_builder_user = nullptr;
+  std::string build_error;  // set when the callback fails; add_mesh then returns 0xFFFFFFFF
   // MeshServer
   std::vector<MeshData> meshes;
   std::unordered_map<std::string, uint32_t> by_desc;

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <string>
+
 #include "host.hpp"
 
 namespace mirth {
@@ -32,12 +34,28 @@ uint32_t Scene::add_mesh(const std::string &desc, Mesh mesh) {
   // the worker then builds the BLAS (src/mesh.rs:118-145).
   auto it = by_desc.find(desc);
   if (it != by_desc.end()) return it->second;
-  BLAS blas(std::move(mesh));
   MeshData d;
-  d.aabb = blas.nodes[0].bounds;
-  d.nodes.reserve(blas.nodes.size());
-  for (const BVHNode &n : blas.nodes) d.nodes.push_back(to_gpu(n));
-  d.mesh = std::move(blas.mesh);
+  if (blas_builder != nullptr && mesh.n_faces() != 0) {
+    // the caller's builder (the device one) stands in for BLAS::new
+    const uint32_t nf = (uint32_t)mesh.n_faces();
+    d.nodes.resize(2 * (size_t)nf);
+    uint32_t n_nodes = 0;
+    const int rc = blas_builder(blas_builder_user, &mesh.positions[0].x, (uint32_t)mesh.positions.size(),
+                                mesh.faces.data(), nf, d.nodes.data(), (uint32_t)d.nodes.size(), &n_nodes);
+    if (rc != 0 || n_nodes == 0 || n_nodes > d.nodes.size()) {
+      build_error = "add_mesh: the BLAS builder callback failed with status " + std::to_string(rc);
+      return 0xFFFFFFFFu;
+    }
+    d.nodes.resize(n_nodes);
+    d.aabb = AABB{{d.nodes[0].lb[0], d.nodes[0].lb[1], d.nodes[0].lb[2]}, {d.nodes[0].ub[0], d.nodes[0].ub[1], d.nodes[0].ub[2]}};
+    d.mesh = std::move(mesh);
+  } else {
+    BLAS blas(std::move(mesh));
+    d.aabb = blas.nodes[0].bounds;
+    d.nodes.reserve(blas.nodes.size());
+    for (const BVHNode &n : blas.nodes) d.nodes.push_back(to_gpu(n));
+    d.mesh = std::move(blas.mesh);
+  }
   meshes.push_back(std::move(d));
   uint32_t id = (uint32_t)meshes.size() - 1;
   by_desc.emplace(desc, id);

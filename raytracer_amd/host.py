@@ -70,6 +70,20 @@ def make_sample_sources(width, height, seed, shuffle=2):
     return out
 
 
+def build_blas(positions4, faces4):
+    """BLAS::new on the host, on positions as given: (reordered faces[m,4], nodes[k])."""
+    L = ffi.host_lib()
+    pos = np.ascontiguousarray(positions4, "<f4").reshape(-1, 4)
+    faces = np.array(faces4, "<u4").reshape(-1, 4)  # a copy: the build reorders it in place
+    nodes = np.zeros(max(2 * len(faces), 1), ffi.BVHNode)
+    n = C.c_uint32()
+    rc = L.mirth_build_blas_host(pos.ctypes.data, len(pos), faces.ctypes.data, len(faces), nodes.ctypes.data,
+                                 len(nodes), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("mirth_build_blas_host failed")
+    return faces, nodes[:n.value].copy()
+
+
 class Scene:
     """MeshServer + MaterialServer + entity list + binder."""
 
@@ -95,6 +109,12 @@ class Scene:
         if rc < 0:
             raise RuntimeError(f"{what}: {self._L.mirth_last_error(self._h).decode()}")
         return rc
+
+    def set_blas_builder(self, pathtracer):
+        """Meshes loaded from now on get their BLAS from `pathtracer`'s device (None: the host builder)."""
+        self._builder = None if pathtracer is None else pathtracer.blas_builder_callback()  # keeps the thunk alive
+        fn = None if self._builder is None else C.cast(self._builder, C.c_void_p)
+        self._check(self._L.mirth_set_blas_builder(self._h, fn, None), "set_blas_builder")
 
     # MeshServer ---------------------------------------------------------
     def load_obj(self, path):

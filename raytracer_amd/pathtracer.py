@@ -138,6 +138,28 @@ class Pathtracer:
                                            C.byref(c) if want_counts else None), "mirt_trace_any")
         return (out, c) if want_counts else out
 
+    # ---- BLAS build ---------------------------------------------------
+    def build_blas(self, positions4, faces4):
+        """BLAS::new on the device: (reordered faces[m,4], nodes[k], device ms)."""
+        pos = np.ascontiguousarray(positions4, "<f4").reshape(-1, 4)
+        faces = np.array(faces4, "<u4").reshape(-1, 4)  # a copy: the build reorders it in place
+        nodes = np.zeros(max(2 * len(faces), 1), ffi.BVHNode)
+        n, ms = C.c_uint32(), C.c_float()
+        self._check(self._L.mirt_build_blas(self._h, pos.ctypes.data, len(pos), faces.ctypes.data, len(faces),
+                                            nodes.ctypes.data, len(nodes), C.byref(n), C.byref(ms)), "mirt_build_blas")
+        return faces, nodes[:n.value].copy(), ms.value
+
+    def blas_builder_callback(self):
+        """(function pointer, user pointer) for Scene.set_blas_builder: mirt_build_blas on this context."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                            C.c_uint32, C.POINTER(C.c_uint32))
+        L, h = self._L, self._h
+
+        def on_device(user, pos, n_pos, faces, n_faces, nodes, cap, n_nodes):
+            return L.mirt_build_blas(h, pos, n_pos, faces, n_faces, nodes, cap, n_nodes, None)
+
+        return proto(on_device)
+
     def bench_trace_closest(self, rays, repeats=10):
         rays = np.ascontiguousarray(rays, ffi.Ray)
         ms = C.c_double()

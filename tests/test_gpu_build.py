@@ -1,0 +1,132 @@
+"""GPU tests of the device BLAS builder (mirt_build_blas) against the host
+builder, which restates BLAS::new / BVH::initialize of the reference
+(src/blas.rs:62-78, src/bvh.rs:52-178) and is itself pinned by the hand-traced
+cube and the pure-Python builder in tests/test_oracle_kat.py.
+
+Bar: the reordered face array and the node array (boxes, children, skip links,
+ranges) are compared BYTE FOR BYTE.
+"""
+import time
+
+import numpy as np
+import pytest
+
+from raytracer_amd import ffi, host, pathtracer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pt():
+    p = pathtracer.Pathtracer(0)
+    yield p
+    p.close()
+
+
+def faces_of(indices):
+    f = np.zeros((len(indices) // 3, 4), "<u4")
+    f[:, :3] = np.asarray(indices, "<u4").reshape(-1, 3)
+    return f
+
+
+def positions4(xyz):
+    p = np.ones((len(xyz), 4), "<f4")  # Mesh::positions carry w = 1
+    p[:, :3] = xyz
+    return p
+
+
+def assert_same_blas(pt, name, xyz, indices):
+    pos, faces0 = positions4(xyz), faces_of(indices)
+    want_faces, want_nodes = host.build_blas(pos, faces0)
+    faces, nodes, _ = pt.build_blas(pos, faces0)
+    assert np.array_equal(faces, want_faces), name
+    assert len(nodes) == len(want_nodes), (name, len(nodes), len(want_nodes))
+    assert nodes.tobytes() == want_nodes.tobytes(), name
+
+
+def soup(rng, n_vertices, n_faces):
+    positions = rng.uniform(-1.0, 1.0, (n_vertices, 3)).astype("<f4")
+    indices = rng.integers(0, n_vertices, (n_faces, 3)).astype("<u4")
+    return positions, indices.reshape(-1)
+
+
+@pytest.mark.parametrize("n_faces", [1, 2, 4, 5, 6, 7, 12, 63, 64, 65, 300, 2047, 2048, 2049, 5000, 70000])
+def test_triangle_soups_of_every_size_class(pt, n_faces):
+    # sizes around the leaf threshold (4), one wave (64) and the switch to the
+    # 1024-thread block shape (2048)
+    rng = np.random.default_rng(n_faces)
+    positions, indices = soup(rng, max(3, n_faces // 2 + 3), n_faces)
+    assert_same_blas(pt, f"soup{n_faces}", positions, indices)
+
+
+def test_one_sided_partitions_and_equal_centroids(pt):
+    rng = np.random.default_rng(5)
+    # (a) many copies of one triangle: every centroid equal, the partition puts everything right,
+    #     the node stays a leaf of thousands of triangles while its faces are still permuted
+    positions = rng.uniform(-1.0, 1.0, (6, 3)).astype("<f4")
+    indices = np.tile(np.array([0, 1, 2], "<u4"), 3000)
+    indices[:9] = [3, 4, 5, 0, 1, 2, 1, 2, 3]
+    assert_same_blas(pt, "copies", positions, indices)
+    # (b) clusters of coincident triangles among ordinary ones: deep, lopsided trees with
+    #     bail-out leaves of mixed sizes
+    positions, indices = soup(rng, 500, 6000)
+    tri = indices.reshape(-1, 3)
+    tri[1000:1800] = tri[1000]
+    tri[3000:3005] = tri[3000]
+    tri[4000:6000:2] = tri[4000]
+    assert_same_blas(pt, "clusters", positions, tri.reshape(-1))
+    # (c) grid-aligned geometry: many equal coordinates, ties in the axis choice, centroids on the split
+    g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(3), indexing="ij"), -1).reshape(-1, 3)
+    positions = g.astype("<f4")
+    indices = rng.integers(0, len(positions), (4000, 3)).astype("<u4").reshape(-1)
+    assert_same_blas(pt, "grid", positions, indices)
+
+
+def test_signed_zero_bounds_follow_the_first_occurrence(pt):
+    # coordinates that are +0 or -0 at random: the sign of a zero bound is that of the first
+    # element in order, as the host's sequential fold keeps it — in leaves and in inner nodes
+    rng = np.random.default_rng(9)
+    n_vertices = 400
+    xyz = rng.uniform(-1.0, 1.0, (n_vertices, 3)).astype("<f4")
+    xyz[:, 2] = np.where(rng.random(n_vertices) < 0.5, 0.0, -0.0)
+    xyz[::3, 0] = np.where(rng.random(len(xyz[::3])) < 0.5, 0.0, -0.0)
+    indices = rng.integers(0, n_vertices, (3000, 3)).astype("<u4").reshape(-1)
+    assert np.signbit(xyz[:, 2]).any() and not np.signbit(xyz[:, 2]).all()
+    assert_same_blas(pt, "zeros", xyz, indices)
+
+
+@pytest.mark.parametrize("cfg", [1, 2])
+def test_scene_built_on_the_device_equals_the_host_build(pt, config_scenes, cfg):
+    # the host model with the device builder plugged in (OBJ meshes, rect): identical flat buffers
+    want, _ = config_scenes(cfg)
+    s = host.Scene()
+    s.set_blas_builder(pt)
+    s.build_config(cfg)
+    got = s.bind()
+    s.close()
+    for key in ("indices", "blas_nodes", "tlas_nodes", "vertices", "tlas_to_instances"):
+        assert np.asarray(got[key]).tobytes() == np.asarray(want[key]).tobytes(), key
+
+
+def test_dragon_class_mesh_at_full_size(pt, config_scenes):
+    # config 3's 871 040-triangle mesh: byte-identical faces and nodes, and the time it takes
+    want, _ = config_scenes(3)
+    t0 = time.perf_counter()
+    s = host.Scene()
+    s.set_blas_builder(pt)
+    s.build_config(3)
+    got = s.bind()
+    s.close()
+    dt = time.perf_counter() - t0
+    for key in ("indices", "blas_nodes", "tlas_nodes"):
+        assert np.asarray(got[key]).tobytes() == np.asarray(want[key]).tobytes(), key
+    print(f"config 3 scene with the device builder: {dt:.2f} s")
+
+
+def test_bad_arguments_are_refused(pt):
+    pos = np.zeros((3, 4), "<f4")
+    faces = np.array([[0, 1, 7, 0]], "<u4")  # index out of range
+    with pytest.raises(pathtracer.MirtError):
+        pt.build_blas(pos, faces)
+    faces, nodes, _ = pt.build_blas(pos, np.zeros((0, 4), "<u4"))  # the empty mesh keeps its root leaf
+    assert len(nodes) == 1 and nodes[0]["is_leaf"] == 1 and len(faces) == 0

@@ -102,6 +102,54 @@ def test_suzanne_builder_matches_python_restatement():
         assert [list(lb), list(ub), left, skip, leaf, start, end] == r
 
 
+def test_standalone_host_builder_and_builder_callback():
+    # mirth_build_blas_host on raw positions against the pure-Python builder, and the
+    # builder callback of the host model (the hook the device builder plugs into) fed
+    # with that same host builder: identical scene buffers
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    pos = np.ones((40, 4), "<f4")
+    pos[:, :3] = rng.uniform(-1.0, 1.0, (40, 3))
+    faces = np.zeros((150, 4), "<u4")
+    faces[:, :3] = rng.integers(0, 40, (150, 3))
+    faces[60:75] = faces[60]  # coincident triangles: a leaf the partition cannot split
+    got_faces, got_nodes = host.build_blas(pos, faces)
+    pnodes, pfaces = host_ref.build_blas([p for p in pos], faces.tolist())
+    assert got_faces.tolist() == [list(map(int, f)) for f in pfaces]
+    want = host_ref.nodes_as_records(pnodes)
+    assert len(want) == len(got_nodes)
+    for (lb, ub, left, skip, leaf, start, end), n in zip(want, got_nodes):
+        assert (list(lb), list(ub)) == ([float(x) for x in n["lb"][:3]], [float(x) for x in n["ub"][:3]])
+        assert (left, skip, leaf, start, end) == (n["left"], n["right"], n["is_leaf"], n["start"], n["end"])
+
+    L = ffi.host_lib()
+    proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                        C.POINTER(C.c_uint32))
+    calls = []
+
+    def via_host(user, p, n_p, f, n_f, nodes, cap, n_nodes):
+        calls.append(n_f)
+        return L.mirth_build_blas_host(p, n_p, f, n_f, nodes, cap, n_nodes)
+
+    thunk = proto(via_host)
+    want_arrays, _ = host.build_config_scene(1)
+    s = host.Scene()
+    s._check(L.mirth_set_blas_builder(s._h, C.cast(thunk, C.c_void_p), None), "set_blas_builder")
+    s.build_config(1)
+    got_arrays = s.bind()
+    s.close()
+    assert sorted(calls) == [2, 968]  # rect and suzanne went through the callback
+    for key in ("indices", "blas_nodes", "tlas_nodes", "vertices"):
+        assert np.asarray(got_arrays[key]).tobytes() == np.asarray(want_arrays[key]).tobytes(), key
+    # a failing callback fails the load instead of leaving a half-built mesh behind
+    bad = proto(lambda *a: 7)
+    s = host.Scene()
+    s._check(L.mirth_set_blas_builder(s._h, C.cast(bad, C.c_void_p), None), "set_blas_builder")
+    with pytest.raises(RuntimeError):
+        s.load_cube()
+    s.close()
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
