@@ -201,7 +201,7 @@ def main():
                                 "blas_nodes": counts.blas_nodes / max(counts.rays, 1),
                                 "triangles": counts.triangles / max(counts.rays, 1)}}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
         geometry = "procedural dragon-class knot, 871040 triangles" if info.procedural_dragon else "dragon asset"
         out = {

@@ -88,32 +88,50 @@ __device__ __forceinline__ uint32_t ord_key(float v) {
 template <int NT>
 struct BlockTmp {
   uint32_t w[16];
+  uint32_t w4[4][16];
   unsigned long long k[16];
   float f[16];
 };
 
-// exclusive count of `flag` over the block in thread order; `total` for everyone
+// Exclusive count of flags over four consecutive tiles of NT elements (element
+// j * NT + thread of the group): out[j] for this thread's element of tile j,
+// `total` for everyone.  One barrier pair per 4 * NT elements.
 template <int NT>
-__device__ __forceinline__ uint32_t block_excl_count(BlockTmp<NT> &sh, bool flag, uint32_t &total) {
-  const unsigned long long m = __ballot(flag);
-  const uint32_t rank = b_rank(m);
+__device__ __forceinline__ void block_excl_count4(BlockTmp<NT> &sh, const bool (&flag)[4], uint32_t (&out)[4],
+                                                  uint32_t &total) {
+  unsigned long long m[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m[j] = __ballot(flag[j]);
+  uint32_t run = 0u;
   if (NT == 64) {
-    total = (uint32_t)__popcll(m);
-    return rank;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      out[j] = run + b_rank(m[j]);
+      run += (uint32_t)__popcll(m[j]);
+    }
+    total = run;
+    return;
   }
   const uint32_t wid = threadIdx.x >> 6;
-  if (b_lane() == 0u) sh.w[wid] = (uint32_t)__popcll(m);
-  __syncthreads();
-  uint32_t pre = 0u, tot = 0u;
+  if (b_lane() == 0u) {
 #pragma unroll
-  for (uint32_t w = 0; w < NT / 64; ++w) {
-    const uint32_t c = sh.w[w];
-    pre += w < wid ? c : 0u;
-    tot += c;
+    for (int j = 0; j < 4; ++j) sh.w4[j][wid] = (uint32_t)__popcll(m[j]);
   }
   __syncthreads();
-  total = tot;
-  return pre + rank;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t pre = 0u, tot = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < NT / 64; ++w) {
+      const uint32_t c = sh.w4[j][w];
+      pre += w < wid ? c : 0u;
+      tot += c;
+    }
+    out[j] = run + pre + b_rank(m[j]);
+    run += tot;
+  }
+  __syncthreads();
+  total = run;
 }
 
 template <int NT>
@@ -177,6 +195,7 @@ template <int NT>
 __device__ __forceinline__ void range_bounds(BlockTmp<NT> &sh, const BuildBufs &bb, uint32_t a, uint32_t b, float lb[3],
                                              float ub[3]) {
   unsigned long long kmin[3] = {~0ull, ~0ull, ~0ull}, kmax[3] = {~0ull, ~0ull, ~0ull};
+#pragma unroll 4
   for (uint32_t p = a + threadIdx.x; p < b; p += NT) {
     const uint32_t f = bb.perm[p];
     const float4 mn = bb.bmn[f], mx = bb.bmx[f];
@@ -258,6 +277,7 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
 
   // split = midpoint of the centroids' range on that axis (src/bvh.rs:94-103)
   float cmin = FLT_MAX, cmax = -FLT_MAX;
+#pragma unroll 4
   for (uint32_t p = tid; p < n; p += NT) {
     const float c = centroid(p);
     cmin = c < cmin ? c : cmin;
@@ -269,25 +289,41 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
 
   // from the front: R count before every element, table of the R's
   uint32_t n_r = 0u;
-  for (uint32_t base = 0; base < n; base += NT) {
-    const uint32_t p = base + tid;
-    const bool is_r = p < n && !(centroid(p) < split);
-    uint32_t tot;
-    const uint32_t ex_r = n_r + block_excl_count<NT>(sh, is_r, tot);
-    if (p < n) bb.rl[s + p] = ex_r | (is_r ? 0x80000000u : 0u);
-    if (is_r) bb.pos_r[s + ex_r] = p;
+  for (uint32_t base = 0; base < n; base += 4u * NT) {
+    bool is_r[4];
+    uint32_t ex[4], tot;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t p = base + (uint32_t)j * NT + tid;
+      is_r[j] = p < n && !(centroid(p) < split);
+    }
+    block_excl_count4<NT>(sh, is_r, ex, tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t p = base + (uint32_t)j * NT + tid;
+      if (p < n) bb.rl[s + p] = (n_r + ex[j]) | (is_r[j] ? 0x80000000u : 0u);
+      if (is_r[j]) bb.pos_r[s + n_r + ex[j]] = p;
+    }
     n_r += tot;
   }
   __syncthreads();
   // from the back: L count behind every element, table of the L's
   uint32_t n_l = 0u;
-  for (uint32_t base = 0; base < n; base += NT) {
-    const uint32_t k = base + tid;
-    const bool is_l = k < n && (bb.rl[s + n - 1u - k] & 0x80000000u) == 0u;
-    uint32_t tot;
-    const uint32_t ex_l = n_l + block_excl_count<NT>(sh, is_l, tot);
-    if (k < n) bb.lr[s + n - 1u - k] = ex_l;
-    if (is_l) bb.pos_lb[s + ex_l] = k;
+  for (uint32_t base = 0; base < n; base += 4u * NT) {
+    bool is_l[4];
+    uint32_t ex[4], tot;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t k = base + (uint32_t)j * NT + tid;
+      is_l[j] = k < n && (bb.rl[s + n - 1u - k] & 0x80000000u) == 0u;
+    }
+    block_excl_count4<NT>(sh, is_l, ex, tot);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t k = base + (uint32_t)j * NT + tid;
+      if (k < n) bb.lr[s + n - 1u - k] = n_l + ex[j];
+      if (is_l[j]) bb.pos_lb[s + n_l + ex[j]] = k;
+    }
     n_l += tot;
   }
   __syncthreads();
@@ -297,6 +333,9 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   uint32_t my_l = 0u;
   if (tid == 0u) sh_unt = 0xFFFFFFFFu;
   __syncthreads();
+  const uint32_t *__restrict__ perm_in = bb.perm;
+  uint32_t *__restrict__ perm_out = bb.perm2;
+#pragma unroll 4
   for (uint32_t p = tid; p < n; p += NT) {
     const uint32_t w = bb.rl[s + p];
     const bool is_r = (w & 0x80000000u) != 0u;
@@ -306,14 +345,14 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
     const unsigned long long fr = ml < n_r ? (unsigned long long)bb.pos_r[s + ml] : kInf;
     const bool t_f = (unsigned long long)p + prev_b < (unsigned long long)(n - 1u);
     const bool t_b = (unsigned long long)k + fr + 1ull < (unsigned long long)(n - 1u);
-    const uint32_t f = bb.perm[s + p];
+    const uint32_t f = perm_in[s + p];
     if (t_f) {
       const uint32_t d = is_r ? n - 1u - (uint32_t)prev_b : p;
-      bb.perm2[s + d] = f;
+      perm_out[s + d] = f;
       my_l += is_r ? 0u : 1u;
     } else if (t_b) {
       const uint32_t d = is_r ? p - 1u : (uint32_t)fr;
-      bb.perm2[s + d] = f;
+      perm_out[s + d] = f;
       my_l += is_r ? 0u : 1u;
     } else {
       sh_unt = f;  // exactly one element is never tested
@@ -324,7 +363,12 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   if (tid == 0u) bb.perm2[s + i] = sh_unt;
   __syncthreads();
   // the swaps happen whether or not the node ends up split
-  for (uint32_t p = tid; p < n; p += NT) bb.perm[s + p] = bb.perm2[s + p];
+  {
+    const uint32_t *__restrict__ src = bb.perm2;
+    uint32_t *__restrict__ dst = bb.perm;
+#pragma unroll 4
+    for (uint32_t p = tid; p < n; p += NT) dst[s + p] = src[s + p];
+  }
   __syncthreads();
   if (i == 0u) return;  // one-sided: the node stays a leaf (src/bvh.rs:114-119; i == n cannot happen)
 
