@@ -63,6 +63,8 @@ struct mirt_ctx {
   uint64_t frames_total = 0;
   unsigned long long *h_stats = nullptr;  // pinned, S_COUNT + Q_COUNT words
   unsigned long long *d_trace_counts = nullptr;
+  void *build_ws = nullptr;  // workspace of mirt_build_blas, grown on demand
+  size_t build_ws_bytes = 0;
 };
 
 namespace {
@@ -480,6 +482,7 @@ int mirt_destroy(mirt_ctx *ctx) {
   for (EventPair &ep : ctx->ev_pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
   if (ctx->d_trace_counts) (void)hipFree(ctx->d_trace_counts);
+  if (ctx->build_ws) (void)hipFree(ctx->build_ws);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MIRT_OK;
@@ -1195,7 +1198,7 @@ int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions
     if (faces4[k] >= n_positions) return fail(ctx, MIRT_ERR_BAD_SCENE, "build_blas: face index out of range");
   std::string err;
   const int rc = build_blas_device(ctx->stream, positions4, n_positions, faces4, n_faces, nodes, nodes_capacity, n_nodes,
-                                   device_ms, err);
+                                   device_ms, &ctx->build_ws, &ctx->build_ws_bytes, err);
   if (rc != MIRT_OK) return fail(ctx, rc, err);
   return MIRT_OK;
 }

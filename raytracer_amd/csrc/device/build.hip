@@ -458,18 +458,14 @@ __global__ __launch_bounds__(256) void k_build_faces(BuildBufs bb) {
   if (p < bb.nf) bb.faces_out[p] = bb.faces[bb.perm[p]];
 }
 
-struct DevMem {
-  std::vector<void *> ptrs;
-  ~DevMem() {
-    for (void *p : ptrs) (void)hipFree(p);
-  }
+// Carves 256-byte aligned arrays out of one workspace allocation.
+struct Carver {
+  unsigned char *base;
+  size_t used = 0;
   template <typename T>
-  hipError_t get(T **out, size_t count) {
-    void *p = nullptr;
-    const hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-    if (e == hipSuccess) ptrs.push_back(p);
-    *out = reinterpret_cast<T *>(p);
-    return e;
+  void take(T **out, size_t count) {
+    if (base) *out = reinterpret_cast<T *>(base + used);
+    used += ((count ? count : 1) * sizeof(T) + 255u) & ~(size_t)255u;
   }
 };
 
@@ -486,29 +482,42 @@ struct DevMem {
 
 int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
                       uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
-                      float *device_ms, std::string &err) {
-  DevMem mem;
+                      float *device_ms, void **workspace, size_t *workspace_bytes, std::string &err) {
   BuildBufs bb{};
   bb.nf = n_faces;
   float4 *d_pos = nullptr;
   uint4 *d_faces = nullptr;
   MirtBVHNode *d_out = nullptr;
   const size_t cap = 2 * (size_t)n_faces;  // a split adds two nodes and there are fewer than n_faces splits
-  BUILD_TRY(mem.get(&d_pos, n_positions));
-  BUILD_TRY(mem.get(&d_faces, n_faces));
-  BUILD_TRY(mem.get(&bb.faces_out, n_faces));
-  BUILD_TRY(mem.get(&bb.cen, n_faces));
-  BUILD_TRY(mem.get(&bb.bmn, n_faces));
-  BUILD_TRY(mem.get(&bb.bmx, n_faces));
-  BUILD_TRY(mem.get(&bb.perm, n_faces));
-  BUILD_TRY(mem.get(&bb.perm2, n_faces));
-  BUILD_TRY(mem.get(&bb.rl, n_faces));
-  BUILD_TRY(mem.get(&bb.lr, n_faces));
-  BUILD_TRY(mem.get(&bb.pos_r, n_faces));
-  BUILD_TRY(mem.get(&bb.pos_lb, n_faces));
-  BUILD_TRY(mem.get(&bb.tn, cap));
-  BUILD_TRY(mem.get(&bb.n_tmp, 2));
-  BUILD_TRY(mem.get(&d_out, cap));
+  // one workspace, kept by the caller between builds and grown when a mesh needs more
+  auto carve = [&](unsigned char *base) {
+    Carver c{base};
+    c.take(&d_pos, n_positions);
+    c.take(&d_faces, n_faces);
+    c.take(&bb.faces_out, n_faces);
+    c.take(&bb.cen, n_faces);
+    c.take(&bb.bmn, n_faces);
+    c.take(&bb.bmx, n_faces);
+    c.take(&bb.perm, n_faces);
+    c.take(&bb.perm2, n_faces);
+    c.take(&bb.rl, n_faces);
+    c.take(&bb.lr, n_faces);
+    c.take(&bb.pos_r, n_faces);
+    c.take(&bb.pos_lb, n_faces);
+    c.take(&bb.tn, cap);
+    c.take(&bb.n_tmp, 2);
+    c.take(&d_out, cap);
+    return c.used;
+  };
+  const size_t need = carve(nullptr);
+  if (*workspace == nullptr || *workspace_bytes < need) {
+    if (*workspace) (void)hipFree(*workspace);
+    *workspace = nullptr;
+    *workspace_bytes = 0;
+    BUILD_TRY(hipMalloc(workspace, need));
+    *workspace_bytes = need;
+  }
+  carve(static_cast<unsigned char *>(*workspace));
   bb.pos = d_pos;
   bb.faces = d_faces;
   BUILD_TRY(hipMemcpyAsync(d_pos, positions4, (size_t)n_positions * 16, hipMemcpyHostToDevice, stream));

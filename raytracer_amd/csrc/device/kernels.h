@@ -92,9 +92,11 @@ void launch_math_selftest(hipStream_t stream, const float *a, const float *b, co
 
 // BLAS::new on the device (build.hip): host arrays in, `faces4` reordered in
 // place, nodes in BVHNodeGPU form out.  Face indices must have been checked
-// against n_positions.  Returns a MirtStatus and a message in `err`.
+// against n_positions.  `workspace` / `workspace_bytes` is device memory the
+// caller keeps between builds (grown here with hipMalloc when too small, freed
+// by the caller).  Returns a MirtStatus and a message in `err`.
 int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
                       uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
-                      float *device_ms, std::string &err);
+                      float *device_ms, void **workspace, size_t *workspace_bytes, std::string &err);
 
 }  // namespace mirt
