@@ -55,6 +55,8 @@ struct TNode {
 };
 static_assert(sizeof(TNode) == 64, "TNode is one 64-byte record");
 
+struct HugeNode;
+
 struct BuildBufs {
   const float4 *pos;
   const uint4 *faces;
@@ -64,12 +66,31 @@ struct BuildBufs {
   uint32_t *rl, *lr;        // per position: R count before (bit 31: the element is R); L count behind
   uint32_t *pos_r, *pos_lb; // m-th R from the front -> front index; m-th L from the back -> back index
   TNode *tn;
-  uint32_t *n_tmp;          // [0] nodes created so far, [1] how many of them got kBigNode elements or more
+  uint32_t *n_tmp;          // [0] nodes created so far, [1] / [2] how many of them got kBigNode / kHugeNode elements or more
+  HugeNode *huge;           // the level's huge nodes
+  uint32_t *huge_hdr;       // [0] how many, [1] their chunks in all
+  uint32_t *chunk_node;     // chunk -> index into huge[]
+  uint32_t *chunk_r;        // R's in the chunk, then (after the scan) R's before it in its node
+  uint32_t *chunk_lb;       // L's behind the chunk in its node
   uint32_t nf;
 };
 
 constexpr uint32_t kLeafMax = 4u;      // BLAS::new: initialize(4)
 constexpr uint32_t kBigNode = 2048u;   // nodes this big get a 1024-thread block
+constexpr uint32_t kHugeNode = 16384u; // nodes this big are split by many blocks, kChunk elements each
+constexpr uint32_t kChunk = 4096u;     // four elements per thread of a 1024-thread block
+
+// A node that many blocks split together: what they share between kernels.
+struct HugeNode {
+  uint32_t id, s, n, axis;
+  uint32_t kmin, kmax;       // ordered keys of the centroid range on the axis
+  uint32_t n_r, n_l;         // R's and L's in the node
+  uint32_t i;                // tested L's = the split point
+  uint32_t unt;              // face id of the element that is never tested
+  uint32_t chunk0, n_chunks; // its chunks in the level's chunk list
+  uint32_t pad[4];
+  unsigned long long bk[12]; // box keys: left min xyz, left max xyz, right min xyz, right max xyz
+};
 
 __device__ __forceinline__ float hmin2(float a, float b) { return b < a ? b : a; }  // first operand on ties
 __device__ __forceinline__ float hmax2(float a, float b) { return b > a ? b : a; }
@@ -249,7 +270,63 @@ __global__ __launch_bounds__(1024) void k_build_root(BuildBufs bb) {
     bb.tn[0] = n;
     bb.n_tmp[0] = 1u;
     bb.n_tmp[1] = bb.nf >= kBigNode ? 1u : 0u;
+    bb.n_tmp[2] = bb.nf >= kHugeNode ? 1u : 0u;
   }
+}
+
+// the longest axis of a node's box (src/bvh.rs:81-88)
+__device__ __forceinline__ int split_axis(const TNode &node) {
+  const float ex = node.ub[0] - node.lb[0], ey = node.ub[1] - node.lb[1], ez = node.ub[2] - node.lb[2];
+  int axis = 0;
+  if (ey > ex) axis = 1;
+  if (ez > (axis == 0 ? ex : ey)) axis = 2;
+  return axis;
+}
+
+// Where the partition loop leaves the element at front index p of a node with
+// n elements, n_r R's and n_l L's (closed form at the top of this file).
+// Returns false for the one element that is never tested; `tested_l` says
+// whether a placed element counts towards the split point.
+__device__ __forceinline__ bool place_element(const BuildBufs &bb, uint32_t s, uint32_t n, uint32_t n_r, uint32_t n_l,
+                                              uint32_t p, uint32_t &dest, bool &tested_l) {
+  const unsigned long long kInf = 1ull << 40;
+  const uint32_t w = bb.rl[s + p];
+  const bool is_r = (w & 0x80000000u) != 0u;
+  const uint32_t m1 = w & 0x7FFFFFFFu;  // R's before p
+  const unsigned long long prev_b = m1 == 0u ? 0ull : (m1 - 1u < n_l ? (unsigned long long)bb.pos_lb[s + m1 - 1u] + 1ull : kInf);
+  const uint32_t k = n - 1u - p, ml = bb.lr[s + p];  // L's behind p
+  const unsigned long long fr = ml < n_r ? (unsigned long long)bb.pos_r[s + ml] : kInf;
+  const bool t_f = (unsigned long long)p + prev_b < (unsigned long long)(n - 1u);
+  const bool t_b = (unsigned long long)k + fr + 1ull < (unsigned long long)(n - 1u);
+  tested_l = (t_f || t_b) && !is_r;
+  if (t_f) dest = is_r ? n - 1u - (uint32_t)prev_b : p;
+  else if (t_b) dest = is_r ? p - 1u : (uint32_t)fr;
+  return t_f || t_b;
+}
+
+// The two children of node `id` split at s + i (src/bvh.rs:121-137), as leaves with their boxes.
+__device__ __forceinline__ void make_children(const BuildBufs &bb, uint32_t id, uint32_t s, uint32_t n, uint32_t i,
+                                              const float llb[3], const float lub[3], const float rlb[3],
+                                              const float rub[3]) {
+  const uint32_t c = atomicAdd(&bb.n_tmp[0], 2u);
+  const uint32_t big = (i >= kBigNode ? 1u : 0u) + (n - i >= kBigNode ? 1u : 0u);
+  if (big != 0u) atomicAdd(&bb.n_tmp[1], big);
+  const uint32_t huge = (i >= kHugeNode ? 1u : 0u) + (n - i >= kHugeNode ? 1u : 0u);
+  if (huge != 0u) atomicAdd(&bb.n_tmp[2], huge);
+  TNode l{}, r{};
+  for (int ax = 0; ax < 3; ++ax) {
+    l.lb[ax] = llb[ax];
+    l.ub[ax] = lub[ax];
+    r.lb[ax] = rlb[ax];
+    r.ub[ax] = rub[ax];
+  }
+  l.s = s;
+  l.e = s + i;
+  r.s = s + i;
+  r.e = s + n;
+  bb.tn[c] = l;
+  bb.tn[c + 1u] = r;
+  bb.tn[id].child = c;
 }
 
 // subdivide (src/bvh.rs:68-157) for the nodes [first, first + gridDim.x) of one
@@ -262,14 +339,10 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   const TNode node = bb.tn[id];
   const uint32_t s = node.s, n = node.e - node.s;
   if (n <= kLeafMax) return;
-  if ((NT == 1024) != (n >= kBigNode)) return;
+  if ((NT == 1024) != (n >= kBigNode) || n >= kHugeNode) return;
   const uint32_t tid = threadIdx.x;
 
-  // the longest axis of the node's box (src/bvh.rs:81-88)
-  const float ex = node.ub[0] - node.lb[0], ey = node.ub[1] - node.lb[1], ez = node.ub[2] - node.lb[2];
-  int axis = 0;
-  if (ey > ex) axis = 1;
-  if (ez > (axis == 0 ? ex : ey)) axis = 2;
+  const int axis = split_axis(node);
   auto centroid = [&](uint32_t p) {
     const float4 c = bb.cen[bb.perm[s + p]];
     return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
@@ -329,7 +402,6 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   __syncthreads();
 
   // every tested element to its place; count the tested L's
-  const unsigned long long kInf = 1ull << 40;
   uint32_t my_l = 0u;
   if (tid == 0u) sh_unt = 0xFFFFFFFFu;
   __syncthreads();
@@ -337,23 +409,12 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   uint32_t *__restrict__ perm_out = bb.perm2;
 #pragma unroll 4
   for (uint32_t p = tid; p < n; p += NT) {
-    const uint32_t w = bb.rl[s + p];
-    const bool is_r = (w & 0x80000000u) != 0u;
-    const uint32_t m1 = w & 0x7FFFFFFFu;  // R's before p
-    const unsigned long long prev_b = m1 == 0u ? 0ull : (m1 - 1u < n_l ? (unsigned long long)bb.pos_lb[s + m1 - 1u] + 1ull : kInf);
-    const uint32_t k = n - 1u - p, ml = bb.lr[s + p];  // L's behind p
-    const unsigned long long fr = ml < n_r ? (unsigned long long)bb.pos_r[s + ml] : kInf;
-    const bool t_f = (unsigned long long)p + prev_b < (unsigned long long)(n - 1u);
-    const bool t_b = (unsigned long long)k + fr + 1ull < (unsigned long long)(n - 1u);
+    uint32_t d = 0u;
+    bool tl = false;
     const uint32_t f = perm_in[s + p];
-    if (t_f) {
-      const uint32_t d = is_r ? n - 1u - (uint32_t)prev_b : p;
+    if (place_element(bb, s, n, n_r, n_l, p, d, tl)) {
       perm_out[s + d] = f;
-      my_l += is_r ? 0u : 1u;
-    } else if (t_b) {
-      const uint32_t d = is_r ? p - 1u : (uint32_t)fr;
-      perm_out[s + d] = f;
-      my_l += is_r ? 0u : 1u;
+      my_l += tl ? 1u : 0u;
     } else {
       sh_unt = f;  // exactly one element is never tested
     }
@@ -375,25 +436,258 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   float llb[3], lub[3], rlb[3], rub[3];
   range_bounds<NT>(sh, bb, s, s + i, llb, lub);
   range_bounds<NT>(sh, bb, s + i, s + n, rlb, rub);
-  if (tid == 0u) {
-    const uint32_t c = atomicAdd(&bb.n_tmp[0], 2u);
-    const uint32_t big = (i >= kBigNode ? 1u : 0u) + (n - i >= kBigNode ? 1u : 0u);
-    if (big != 0u) atomicAdd(&bb.n_tmp[1], big);
-    TNode l{}, r{};
-    for (int ax = 0; ax < 3; ++ax) {
-      l.lb[ax] = llb[ax];
-      l.ub[ax] = lub[ax];
-      r.lb[ax] = rlb[ax];
-      r.ub[ax] = rub[ax];
+  if (tid == 0u) make_children(bb, id, s, n, i, llb, lub, rlb, rub);
+}
+
+// ---------------------------------------------------------------- huge nodes
+// A node of kHugeNode elements or more would keep one block — one CU — busy for
+// milliseconds, so the few such nodes of a level are split by all blocks
+// together, kChunk elements per block, in a sequence of short kernels that
+// meet in the node's HugeNode record.  The arithmetic is that of k_build_split.
+
+__device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of ord_key (a zero comes back as +0)
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+// The level's huge nodes and their chunks (one block).
+__global__ __launch_bounds__(1024) void k_huge_list(BuildBufs bb, uint32_t first, uint32_t count) {
+  __shared__ uint32_t sh_n;
+  if (threadIdx.x == 0u) sh_n = 0u;
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < count; t += 1024u) {
+    const TNode node = bb.tn[first + t];
+    const uint32_t n = node.e - node.s;
+    if (n >= kHugeNode) {
+      const uint32_t b = atomicAdd(&sh_n, 1u);
+      HugeNode h{};
+      h.id = first + t;
+      h.s = node.s;
+      h.n = n;
+      h.axis = (uint32_t)split_axis(node);
+      h.kmin = 0xFFFFFFFFu;
+      h.kmax = 0u;
+      h.n_chunks = (n + kChunk - 1u) / kChunk;
+      for (int q = 0; q < 12; ++q) h.bk[q] = ~0ull;
+      bb.huge[b] = h;
     }
-    l.s = s;
-    l.e = s + i;
-    r.s = s + i;
-    r.e = s + n;
-    bb.tn[c] = l;
-    bb.tn[c + 1u] = r;
-    bb.tn[id].child = c;
   }
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t c = 0u;
+    for (uint32_t b = 0; b < sh_n; ++b) {
+      bb.huge[b].chunk0 = c;
+      c += bb.huge[b].n_chunks;
+    }
+    bb.huge_hdr[0] = sh_n;
+    bb.huge_hdr[1] = c;
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < sh_n; b += 1024u) {
+    const uint32_t c0 = bb.huge[b].chunk0, nc = bb.huge[b].n_chunks;
+    for (uint32_t c = 0; c < nc; ++c) bb.chunk_node[c0 + c] = b;
+  }
+}
+
+struct ChunkRef {
+  uint32_t b, s, n, lo, hi, axis;  // huge node, its range, this chunk's element range [lo, hi) within it
+};
+__device__ __forceinline__ bool chunk_ref(const BuildBufs &bb, ChunkRef &c) {
+  if (blockIdx.x >= bb.huge_hdr[1]) return false;
+  c.b = bb.chunk_node[blockIdx.x];
+  const HugeNode &h = bb.huge[c.b];
+  c.s = h.s;
+  c.n = h.n;
+  c.axis = h.axis;
+  c.lo = (blockIdx.x - h.chunk0) * kChunk;
+  c.hi = c.lo + kChunk < h.n ? c.lo + kChunk : h.n;
+  return true;
+}
+__device__ __forceinline__ float chunk_centroid(const BuildBufs &bb, const ChunkRef &c, uint32_t p) {
+  const float4 v = bb.cen[bb.perm[c.s + p]];
+  return c.axis == 0u ? v.x : (c.axis == 1u ? v.y : v.z);
+}
+
+// centroid range on the axis (src/bvh.rs:94-101)
+__global__ __launch_bounds__(1024) void k_huge_range(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  ChunkRef c;
+  if (!chunk_ref(bb, c)) return;
+  float cmin = FLT_MAX, cmax = -FLT_MAX;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    if (p < c.hi) {
+      const float v = chunk_centroid(bb, c, p);
+      cmin = v < cmin ? v : cmin;
+      cmax = v > cmax ? v : cmax;
+    }
+  }
+  cmin = block_minmax<1024, false>(sh, cmin);
+  cmax = block_minmax<1024, true>(sh, cmax);
+  if (threadIdx.x == 0u) {
+    atomicMin(&bb.huge[c.b].kmin, ord_key(cmin));
+    atomicMax(&bb.huge[c.b].kmax, ord_key(cmax));
+  }
+}
+
+__device__ __forceinline__ float huge_split(const HugeNode &h) {  // src/bvh.rs:103
+  return (key_to_float(h.kmin) + key_to_float(h.kmax)) * 0.5f;
+}
+
+// R's per chunk
+__global__ __launch_bounds__(1024) void k_huge_count(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  ChunkRef c;
+  if (!chunk_ref(bb, c)) return;
+  const float split = huge_split(bb.huge[c.b]);
+  uint32_t mine = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    if (p < c.hi && !(chunk_centroid(bb, c, p) < split)) mine++;
+  }
+  const uint32_t tot = block_sum<1024>(sh, mine);
+  if (threadIdx.x == 0u) bb.chunk_r[blockIdx.x] = tot;
+}
+
+// per node: R's before and L's behind every chunk, totals (one thread per huge node)
+__global__ __launch_bounds__(256) void k_huge_scan(BuildBufs bb) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= bb.huge_hdr[0]) return;
+  HugeNode &h = bb.huge[b];
+  uint32_t run = 0u;
+  for (uint32_t c = 0; c < h.n_chunks; ++c) {
+    const uint32_t r = bb.chunk_r[h.chunk0 + c];
+    const uint32_t size = (c + 1u) * kChunk <= h.n ? kChunk : h.n - c * kChunk;
+    bb.chunk_r[h.chunk0 + c] = run;
+    bb.chunk_lb[h.chunk0 + c] = size - r;  // L's in the chunk, for the pass below
+    run += r;
+  }
+  h.n_r = run;
+  uint32_t behind = 0u;
+  for (uint32_t c = h.n_chunks; c-- > 0u;) {
+    const uint32_t l = bb.chunk_lb[h.chunk0 + c];
+    bb.chunk_lb[h.chunk0 + c] = behind;
+    behind += l;
+  }
+  h.n_l = behind;
+  h.i = 0u;
+  h.unt = 0xFFFFFFFFu;
+}
+
+// the two prefix counts and scatter tables of the chunk's elements
+__global__ __launch_bounds__(1024) void k_huge_tables(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  ChunkRef c;
+  if (!chunk_ref(bb, c)) return;
+  const float split = huge_split(bb.huge[c.b]);
+  const uint32_t r_before = bb.chunk_r[blockIdx.x], l_behind = bb.chunk_lb[blockIdx.x];
+  bool is_r[4];
+  uint32_t ex[4], tot;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    is_r[j] = p < c.hi && !(chunk_centroid(bb, c, p) < split);
+  }
+  block_excl_count4<1024>(sh, is_r, ex, tot);
+  const uint32_t l_chunk = (c.hi - c.lo) - tot;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    if (p >= c.hi) continue;
+    bb.rl[c.s + p] = (r_before + ex[j]) | (is_r[j] ? 0x80000000u : 0u);
+    // L's of the chunk behind p = L's of the chunk - L's up to and including p
+    const uint32_t l_upto = (p - c.lo + 1u) - (ex[j] + (is_r[j] ? 1u : 0u));
+    const uint32_t lr = l_behind + l_chunk - l_upto;
+    bb.lr[c.s + p] = lr;
+    if (is_r[j]) bb.pos_r[c.s + r_before + ex[j]] = p;
+    else bb.pos_lb[c.s + lr] = c.n - 1u - p;
+  }
+}
+
+// every tested element to its place; tested L's counted into the node's split point
+__global__ __launch_bounds__(1024) void k_huge_place(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  ChunkRef c;
+  if (!chunk_ref(bb, c)) return;
+  const uint32_t n_r = bb.huge[c.b].n_r, n_l = bb.huge[c.b].n_l;
+  uint32_t my_l = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    if (p >= c.hi) continue;
+    uint32_t d = 0u;
+    bool tl = false;
+    const uint32_t f = bb.perm[c.s + p];
+    if (place_element(bb, c.s, c.n, n_r, n_l, p, d, tl)) {
+      bb.perm2[c.s + d] = f;
+      my_l += tl ? 1u : 0u;
+    } else {
+      bb.huge[c.b].unt = f;
+    }
+  }
+  const uint32_t tot = block_sum<1024>(sh, my_l);
+  if (threadIdx.x == 0u && tot != 0u) atomicAdd(&bb.huge[c.b].i, tot);
+}
+
+// the new order back into place (the untested element at the split point) and the
+// box keys of the two sides
+__global__ __launch_bounds__(1024) void k_huge_copy(BuildBufs bb) {
+  __shared__ BlockTmp<1024> sh;
+  ChunkRef c;
+  if (!chunk_ref(bb, c)) return;
+  const uint32_t i = bb.huge[c.b].i, unt = bb.huge[c.b].unt;
+  unsigned long long k[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) k[q] = ~0ull;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = c.lo + (uint32_t)j * 1024u + threadIdx.x;
+    if (p >= c.hi) continue;
+    const uint32_t f = p == i ? unt : bb.perm2[c.s + p];
+    bb.perm[c.s + p] = f;
+    if (i == 0u) continue;  // one-sided: no children, no boxes
+    const float4 mn = bb.bmn[f], mx = bb.bmx[f];
+    const float vmn[3] = {mn.x, mn.y, mn.z}, vmx[3] = {mx.x, mx.y, mx.z};
+    const bool right = p >= i;
+    const uint32_t rel = right ? p - i : p;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const unsigned long long k0 = ((unsigned long long)ord_key(vmn[ax]) << 32) | rel;
+      const unsigned long long k1 = ((unsigned long long)(~ord_key(vmx[ax])) << 32) | rel;
+      if (!right) {
+        k[ax] = k0 < k[ax] ? k0 : k[ax];
+        k[3 + ax] = k1 < k[3 + ax] ? k1 : k[3 + ax];
+      } else {
+        k[6 + ax] = k0 < k[6 + ax] ? k0 : k[6 + ax];
+        k[9 + ax] = k1 < k[9 + ax] ? k1 : k[9 + ax];
+      }
+    }
+  }
+  if (i == 0u) return;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const unsigned long long m = block_min_key<1024>(sh, k[q]);
+    if (threadIdx.x == 0u && m != ~0ull) atomicMin(&bb.huge[c.b].bk[q], m);
+  }
+}
+
+// children of the huge nodes that were split (one thread per node)
+__global__ __launch_bounds__(256) void k_huge_finish(BuildBufs bb) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= bb.huge_hdr[0]) return;
+  const HugeNode h = bb.huge[b];
+  if (h.i == 0u) return;  // stays a leaf (src/bvh.rs:114-119)
+  float box[12];
+  for (int q = 0; q < 12; ++q) {
+    const bool right = q >= 6, is_max = (q % 6) >= 3;
+    const int ax = q % 3;
+    const uint32_t pos = (uint32_t)h.bk[q] + (right ? h.i : 0u);
+    const uint32_t f = bb.perm[h.s + pos];
+    const float4 v = is_max ? bb.bmx[f] : bb.bmn[f];
+    box[q] = ax == 0 ? v.x : (ax == 1 ? v.y : v.z);
+  }
+  make_children(bb, h.id, h.s, h.n, h.i, &box[0], &box[3], &box[6], &box[9]);
 }
 
 // Bottom-up over one level: subtree sizes, and the box of an inner node as the
@@ -489,6 +783,8 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
   uint4 *d_faces = nullptr;
   MirtBVHNode *d_out = nullptr;
   const size_t cap = 2 * (size_t)n_faces;  // a split adds two nodes and there are fewer than n_faces splits
+  // a level holds at most n_faces / kHugeNode huge nodes, and their chunks are full but for one per node
+  const size_t max_huge = n_faces / kHugeNode + 1, max_chunks = n_faces / kChunk + max_huge + 1;
   // one workspace, kept by the caller between builds and grown when a mesh needs more
   auto carve = [&](unsigned char *base) {
     Carver c{base};
@@ -505,7 +801,12 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
     c.take(&bb.pos_r, n_faces);
     c.take(&bb.pos_lb, n_faces);
     c.take(&bb.tn, cap);
-    c.take(&bb.n_tmp, 2);
+    c.take(&bb.n_tmp, 3);
+    c.take(&bb.huge, max_huge);
+    c.take(&bb.huge_hdr, 2);
+    c.take(&bb.chunk_node, max_chunks);
+    c.take(&bb.chunk_r, max_chunks);
+    c.take(&bb.chunk_lb, max_chunks);
     c.take(&d_out, cap);
     return c.used;
   };
@@ -542,25 +843,39 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
 
   // grow the tree one level at a time; a level is the run of nodes the previous one created
   std::vector<std::pair<uint32_t, uint32_t>> levels;  // first id, count
-  uint32_t big_now = 0;
-  uint32_t first = 0, count = 1, big_seen = 0;
+  uint32_t big_now = 0, huge_now = 0;
+  uint32_t first = 0, count = 1, big_seen = 0, huge_seen = 0;
   while (count != 0u) {
     levels.push_back({first, count});
-    uint32_t tot[2] = {0, 0};
+    uint32_t tot[3] = {0, 0, 0};
     if (levels.size() == 1) {
-      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 8, hipMemcpyDeviceToHost, stream));
+      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 12, hipMemcpyDeviceToHost, stream));
       BUILD_TRY(hipStreamSynchronize(stream));
     } else {
       tot[1] = big_now;
+      tot[2] = huge_now;
     }
-    // the 1024-thread shape only when this level holds a node of its size class
+    // the shapes for big nodes only when this level holds a node of their size class
+    if (tot[2] != huge_seen) {
+      const dim3 cgrid((unsigned)max_chunks), ngrid((unsigned)((max_huge + 255) / 256));
+      hipLaunchKernelGGL(k_huge_list, dim3(1), dim3(1024), 0, stream, bb, first, count);
+      hipLaunchKernelGGL(k_huge_range, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_count, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_scan, ngrid, dim3(256), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_tables, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_place, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_copy, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_finish, ngrid, dim3(256), 0, stream, bb);
+    }
+    huge_seen = tot[2];
     if (tot[1] != big_seen) hipLaunchKernelGGL((k_build_split<1024>), dim3(count), dim3(1024), 0, stream, bb, first);
     big_seen = tot[1];
     hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
-    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 8, hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 12, hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
     const uint32_t total = tot[0];
     big_now = tot[1];
+    huge_now = tot[2];
     if (total > cap || total < first + count) {
       err = "build_blas: node count out of range";
       return MIRT_ERR_HIP;

@@ -50,10 +50,10 @@ def soup(rng, n_vertices, n_faces):
     return positions, indices.reshape(-1)
 
 
-@pytest.mark.parametrize("n_faces", [1, 2, 4, 5, 6, 7, 12, 63, 64, 65, 300, 2047, 2048, 2049, 5000, 70000])
+@pytest.mark.parametrize("n_faces", [1, 2, 4, 5, 6, 7, 12, 63, 64, 65, 300, 2047, 2048, 2049, 5000, 16383, 16384, 16385, 70000, 200001])
 def test_triangle_soups_of_every_size_class(pt, n_faces):
-    # sizes around the leaf threshold (4), one wave (64) and the switch to the
-    # 1024-thread block shape (2048)
+    # sizes around the leaf threshold (4), one wave (64), the switch to the 1024-thread
+    # block shape (2048) and to nodes split by many blocks (16384, chunks of 4096)
     rng = np.random.default_rng(n_faces)
     positions, indices = soup(rng, max(3, n_faces // 2 + 3), n_faces)
     assert_same_blas(pt, f"soup{n_faces}", positions, indices)
@@ -67,6 +67,14 @@ def test_one_sided_partitions_and_equal_centroids(pt):
     indices = np.tile(np.array([0, 1, 2], "<u4"), 3000)
     indices[:9] = [3, 4, 5, 0, 1, 2, 1, 2, 3]
     assert_same_blas(pt, "copies", positions, indices)
+    # the same with a root that many blocks split together: one-sided at the top, and a big
+    # cluster of coincident triangles below a few ordinary splits
+    indices = np.tile(np.array([0, 1, 2], "<u4"), 40000)
+    assert_same_blas(pt, "copies_huge", positions, indices)
+    positions, indices = soup(rng, 9000, 60000)
+    tri = indices.reshape(-1, 3)
+    tri[5000:45000:2] = tri[5000]
+    assert_same_blas(pt, "clusters_huge", positions, tri.reshape(-1))
     # (b) clusters of coincident triangles among ordinary ones: deep, lopsided trees with
     #     bail-out leaves of mixed sizes
     positions, indices = soup(rng, 500, 6000)
