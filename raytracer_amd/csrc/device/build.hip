@@ -23,8 +23,9 @@
 // Two prefix counts and two scatter tables give every element its place, so a
 // node of any size is partitioned by one thread block with scans.
 //
-// The tree is grown level by level (one block per node, two block shapes by node
-// size).  Nodes get temporary ids in creation order; the reference's ids — the
+// The tree is grown level by level, each level in one pass per size class of
+// node: the few huge nodes by all blocks together, then one 1024-thread block,
+// one wave or one thread per node.  Nodes get temporary ids in creation order; the reference's ids — the
 // two children pushed side by side, then the whole left subtree, then the right
 // one — and the skip links (src/bvh.rs:159-172) follow from subtree sizes in a
 // bottom-up and a top-down sweep over the levels.
@@ -38,6 +39,10 @@
 #include <vector>
 
 #include "kernels.h"
+
+#ifndef MIRT_BUILD_BIG
+#define MIRT_BUILD_BIG 512u
+#endif
 
 namespace mirt {
 
@@ -66,7 +71,7 @@ struct BuildBufs {
   uint32_t *rl, *lr;        // per position: R count before (bit 31: the element is R); L count behind
   uint32_t *pos_r, *pos_lb; // m-th R from the front -> front index; m-th L from the back -> back index
   TNode *tn;
-  uint32_t *n_tmp;          // [0] nodes created so far, [1] / [2] how many of them got kBigNode / kHugeNode elements or more
+  uint32_t *n_tmp;          // [0] nodes created so far, [1] / [2] / [3] how many of them got kBigNode / kHugeNode elements or more / more than kTinyNode
   HugeNode *huge;           // the level's huge nodes
   uint32_t *huge_hdr;       // [0] how many, [1] their chunks in all
   uint32_t *chunk_node;     // chunk -> index into huge[]
@@ -76,7 +81,11 @@ struct BuildBufs {
 };
 
 constexpr uint32_t kLeafMax = 4u;      // BLAS::new: initialize(4)
-constexpr uint32_t kBigNode = 2048u;   // nodes this big get a 1024-thread block
+constexpr uint32_t kBigNode = MIRT_BUILD_BIG;   // nodes this big get a 1024-thread block
+#ifndef MIRT_BUILD_TINY
+#define MIRT_BUILD_TINY 16u
+#endif
+constexpr uint32_t kTinyNode = MIRT_BUILD_TINY;  // nodes up to this size are split by one thread each, with the loop as written
 constexpr uint32_t kHugeNode = 16384u; // nodes this big are split by many blocks, kChunk elements each
 constexpr uint32_t kChunk = 4096u;     // four elements per thread of a 1024-thread block
 
@@ -254,24 +263,48 @@ __global__ __launch_bounds__(256) void k_build_prep(BuildBufs bb) {
   bb.perm[f] = f;
 }
 
-// the root: a leaf over every face (src/blas.rs:64-71) with its box
-__global__ __launch_bounds__(1024) void k_build_root(BuildBufs bb) {
+// the root: a leaf over every face (src/blas.rs:64-71) with its box; the box keys of
+// kChunk faces per block meet in root_keys (all ones before the launch)
+__global__ __launch_bounds__(1024) void k_build_root_keys(BuildBufs bb, unsigned long long *root_keys) {
   __shared__ BlockTmp<1024> sh;
-  float lb[3], ub[3];
-  range_bounds<1024>(sh, bb, 0u, bb.nf, lb, ub);
-  if (threadIdx.x == 0u) {
-    TNode n{};
+  unsigned long long k[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) k[q] = ~0ull;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p = blockIdx.x * kChunk + (uint32_t)j * 1024u + threadIdx.x;
+    if (p >= bb.nf) continue;
+    const float4 mn = bb.bmn[p], mx = bb.bmx[p];  // the order is still the identity
+    const float vmn[3] = {mn.x, mn.y, mn.z}, vmx[3] = {mx.x, mx.y, mx.z};
+#pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-      n.lb[ax] = lb[ax];
-      n.ub[ax] = ub[ax];
+      const unsigned long long k0 = ((unsigned long long)ord_key(vmn[ax]) << 32) | p;
+      const unsigned long long k1 = ((unsigned long long)(~ord_key(vmx[ax])) << 32) | p;
+      k[ax] = k0 < k[ax] ? k0 : k[ax];
+      k[3 + ax] = k1 < k[3 + ax] ? k1 : k[3 + ax];
     }
-    n.s = 0u;
-    n.e = bb.nf;
-    bb.tn[0] = n;
-    bb.n_tmp[0] = 1u;
-    bb.n_tmp[1] = bb.nf >= kBigNode ? 1u : 0u;
-    bb.n_tmp[2] = bb.nf >= kHugeNode ? 1u : 0u;
   }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const unsigned long long m = block_min_key<1024>(sh, k[q]);
+    if (threadIdx.x == 0u && m != ~0ull) atomicMin(&root_keys[q], m);
+  }
+}
+__global__ void k_build_root(BuildBufs bb, const unsigned long long *root_keys) {
+  if (blockIdx.x != 0u || threadIdx.x != 0u) return;
+  TNode n{};
+  for (int ax = 0; ax < 3; ++ax) {
+    const float4 mn = bb.bmn[(uint32_t)root_keys[ax]], mx = bb.bmx[(uint32_t)root_keys[3 + ax]];
+    n.lb[ax] = ax == 0 ? mn.x : (ax == 1 ? mn.y : mn.z);
+    n.ub[ax] = ax == 0 ? mx.x : (ax == 1 ? mx.y : mx.z);
+  }
+  n.s = 0u;
+  n.e = bb.nf;
+  bb.tn[0] = n;
+  bb.n_tmp[0] = 1u;
+  bb.n_tmp[1] = bb.nf >= kBigNode ? 1u : 0u;
+  bb.n_tmp[2] = bb.nf >= kHugeNode ? 1u : 0u;
+  bb.n_tmp[3] = bb.nf > kTinyNode ? 1u : 0u;
 }
 
 // the longest axis of a node's box (src/bvh.rs:81-88)
@@ -313,6 +346,8 @@ __device__ __forceinline__ void make_children(const BuildBufs &bb, uint32_t id, 
   if (big != 0u) atomicAdd(&bb.n_tmp[1], big);
   const uint32_t huge = (i >= kHugeNode ? 1u : 0u) + (n - i >= kHugeNode ? 1u : 0u);
   if (huge != 0u) atomicAdd(&bb.n_tmp[2], huge);
+  const uint32_t wave = (i > kTinyNode ? 1u : 0u) + (n - i > kTinyNode ? 1u : 0u);
+  if (wave != 0u) atomicAdd(&bb.n_tmp[3], wave);
   TNode l{}, r{};
   for (int ax = 0; ax < 3; ++ax) {
     l.lb[ax] = llb[ax];
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   const TNode node = bb.tn[id];
   const uint32_t s = node.s, n = node.e - node.s;
   if (n <= kLeafMax) return;
-  if ((NT == 1024) != (n >= kBigNode) || n >= kHugeNode) return;
+  if ((NT == 1024) != (n >= kBigNode) || n >= kHugeNode || n <= kTinyNode) return;
   const uint32_t tid = threadIdx.x;
 
   const int axis = split_axis(node);
@@ -437,6 +472,55 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   range_bounds<NT>(sh, bb, s, s + i, llb, lub);
   range_bounds<NT>(sh, bb, s + i, s + n, rlb, rub);
   if (tid == 0u) make_children(bb, id, s, n, i, llb, lub, rlb, rub);
+}
+
+// subdivide for the nodes of up to kTinyNode elements, one thread per node: the
+// loops of src/bvh.rs:94-112 and :58-63 as they are written.  Deep levels hold
+// hundreds of thousands of such nodes; a wave apiece would mostly idle.
+__global__ __launch_bounds__(256) void k_build_split_tiny(BuildBufs bb, uint32_t first, uint32_t count) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= count) return;
+  const uint32_t id = first + t;
+  const TNode node = bb.tn[id];
+  const uint32_t s = node.s, e = node.e, n = e - s;
+  if (n <= kLeafMax || n > kTinyNode) return;
+  const int axis = split_axis(node);
+  auto centroid = [&](uint32_t p) {
+    const float4 c = bb.cen[bb.perm[p]];
+    return axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+  };
+  float cmin = centroid(s), cmax = cmin;
+  for (uint32_t p = s + 1u; p < e; ++p) {
+    const float c = centroid(p);
+    cmin = hmin2(cmin, c);
+    cmax = hmax2(cmax, c);
+  }
+  const float split = (cmin + cmax) * 0.5f;
+  uint32_t i = s, j = e - 1u;
+  while (i < j) {
+    if (centroid(i) < split) {
+      i += 1u;
+    } else {
+      const uint32_t a = bb.perm[i], b = bb.perm[j];
+      bb.perm[i] = b;
+      bb.perm[j] = a;
+      j -= 1u;
+    }
+  }
+  if (i == s) return;  // one-sided (i == e cannot happen)
+  float box[12];
+  for (int side = 0; side < 2; ++side) {
+    const uint32_t a = side == 0 ? s : i, b = side == 0 ? i : e;
+    float4 mn = bb.bmn[bb.perm[a]], mx = bb.bmx[bb.perm[a]];
+    for (uint32_t p = a + 1u; p < b; ++p) {
+      const float4 m2 = bb.bmn[bb.perm[p]], x2 = bb.bmx[bb.perm[p]];
+      mn = make_float4(hmin2(mn.x, m2.x), hmin2(mn.y, m2.y), hmin2(mn.z, m2.z), 0.0f);
+      mx = make_float4(hmax2(mx.x, x2.x), hmax2(mx.y, x2.y), hmax2(mx.z, x2.z), 0.0f);
+    }
+    box[side * 6 + 0] = mn.x; box[side * 6 + 1] = mn.y; box[side * 6 + 2] = mn.z;
+    box[side * 6 + 3] = mx.x; box[side * 6 + 4] = mx.y; box[side * 6 + 5] = mx.z;
+  }
+  make_children(bb, id, s, n, i - s, &box[0], &box[3], &box[6], &box[9]);
 }
 
 // ---------------------------------------------------------------- huge nodes
@@ -782,6 +866,7 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
   float4 *d_pos = nullptr;
   uint4 *d_faces = nullptr;
   MirtBVHNode *d_out = nullptr;
+  unsigned long long *root_keys = nullptr;
   const size_t cap = 2 * (size_t)n_faces;  // a split adds two nodes and there are fewer than n_faces splits
   // a level holds at most n_faces / kHugeNode huge nodes, and their chunks are full but for one per node
   const size_t max_huge = n_faces / kHugeNode + 1, max_chunks = n_faces / kChunk + max_huge + 1;
@@ -801,7 +886,8 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
     c.take(&bb.pos_r, n_faces);
     c.take(&bb.pos_lb, n_faces);
     c.take(&bb.tn, cap);
-    c.take(&bb.n_tmp, 3);
+    c.take(&bb.n_tmp, 4);
+    c.take(&root_keys, 6);
     c.take(&bb.huge, max_huge);
     c.take(&bb.huge_hdr, 2);
     c.take(&bb.chunk_node, max_chunks);
@@ -839,21 +925,24 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
 
   const unsigned fblocks = (n_faces + 255u) / 256u;
   hipLaunchKernelGGL(k_build_prep, dim3(fblocks), dim3(256), 0, stream, bb);
-  hipLaunchKernelGGL(k_build_root, dim3(1), dim3(1024), 0, stream, bb);
+  BUILD_TRY(hipMemsetAsync(root_keys, 0xFF, 6 * sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kChunk - 1u) / kChunk), dim3(1024), 0, stream, bb, root_keys);
+  hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, stream, bb, root_keys);
 
   // grow the tree one level at a time; a level is the run of nodes the previous one created
   std::vector<std::pair<uint32_t, uint32_t>> levels;  // first id, count
-  uint32_t big_now = 0, huge_now = 0;
-  uint32_t first = 0, count = 1, big_seen = 0, huge_seen = 0;
+  uint32_t big_now = 0, huge_now = 0, wave_now = 0;
+  uint32_t first = 0, count = 1, big_seen = 0, huge_seen = 0, wave_seen = 0;
   while (count != 0u) {
     levels.push_back({first, count});
-    uint32_t tot[3] = {0, 0, 0};
+    uint32_t tot[4] = {0, 0, 0, 0};
     if (levels.size() == 1) {
-      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 12, hipMemcpyDeviceToHost, stream));
+      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
       BUILD_TRY(hipStreamSynchronize(stream));
     } else {
       tot[1] = big_now;
       tot[2] = huge_now;
+      tot[3] = wave_now;
     }
     // the shapes for big nodes only when this level holds a node of their size class
     if (tot[2] != huge_seen) {
@@ -870,12 +959,15 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
     huge_seen = tot[2];
     if (tot[1] != big_seen) hipLaunchKernelGGL((k_build_split<1024>), dim3(count), dim3(1024), 0, stream, bb, first);
     big_seen = tot[1];
-    hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
-    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 12, hipMemcpyDeviceToHost, stream));
+    if (tot[3] != wave_seen) hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
+    wave_seen = tot[3];
+    hipLaunchKernelGGL(k_build_split_tiny, dim3((count + 255u) / 256u), dim3(256), 0, stream, bb, first, count);
+    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
     BUILD_TRY(hipStreamSynchronize(stream));
     const uint32_t total = tot[0];
     big_now = tot[1];
     huge_now = tot[2];
+    wave_now = tot[3];
     if (total > cap || total < first + count) {
       err = "build_blas: node count out of range";
       return MIRT_ERR_HIP;
