@@ -385,13 +385,16 @@ int seed_slots(mirt_ctx *c) {
   return MIRT_OK;
 }
 
-// `respawn` (uber shading only): the shade kernel accumulates and respawns the
-// paths that end, so after the first frame the sample kernel finds an empty
-// terminate queue and only clears the idle queue counters.
+// `respawn`: the kernel that runs the extend epilogue (the shade kernel with
+// uber shading, k_extend_finish with per-material shading) accumulates and
+// respawns the paths that end in it.  With uber shading the sample kernel then
+// finds an empty terminate queue after the first frame and only clears the idle
+// queue counters; with per-material shading it is left with the paths that end
+// in a material kernel.
 void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample, bool respawn) {
   const LaunchCfg cfg = launch_cfg(c);
   DFrameParams fp = frame_params(c, sample_limit, first_sample);
-  fp.respawn = respawn && c->params.shade_mode != MIRT_SHADE_CLASSIC ? 1u : 0u;
+  fp.respawn = respawn ? 1u : 0u;
   timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
   if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {

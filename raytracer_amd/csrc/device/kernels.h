@@ -56,7 +56,7 @@ struct DFrameParams {
   uint32_t frame;                   // frame parity selects the queue buffers
   uint32_t have_lights;
   uint32_t counting;
-  uint32_t respawn;  // uber shading: paths that end are accumulated and respawned by the shade kernel
+  uint32_t respawn;  // paths that end in the extend epilogue are accumulated and respawned there
 };
 
 // Threads per block of the streaming frame kernels (see block_push2).

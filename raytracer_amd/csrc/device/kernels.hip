@@ -216,19 +216,29 @@ __global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, D
 // path, a hit gets its world-space record and goes to the connect queue or to
 // the queue of its material.  (Uber shading does this inside
 // k_finish_shade_uber.)
+//
+// RESPAWN: a path that ends here (sky, out of bounces, no material) is
+// accumulated and its slot takes the next sample at once, as in
+// k_finish_shade_uber<true>; paths that end in a material kernel still go
+// through the terminate queue and the sample kernel.
+template <bool RESPAWN>
 __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  uint32_t *term_cnt = &st.qcount[Q_TERM0 + (par ^ 1u)];
-  uint32_t *term = st.qdata[Q_TERM0 + (par ^ 1u)];
-  // queue 0: terminate; 1..5: connect and the four material queues, in QueueId order
+  // queue 0: terminate (RESPAWN: the next frame's extension queue, for the respawned slot);
+  // 1..5: connect and the four material queues, in QueueId order
+  const int q0 = RESPAWN ? Q_EXT0 + (int)(par ^ 1u) : Q_TERM0 + (int)(par ^ 1u);
   __shared__ BlockPushN<6> sh;
+  __shared__ BlockReserve shr;
   static_assert(Q_LAMBERTIAN == Q_CONNECT + 1 && Q_EMISSIVE == Q_CONNECT + 4, "routes index consecutive queues");
-  uint32_t *const counts[6] = {term_cnt, &st.qcount[Q_CONNECT], &st.qcount[Q_LAMBERTIAN], &st.qcount[Q_METALLIC],
+  uint32_t *const counts[6] = {&st.qcount[q0], &st.qcount[Q_CONNECT], &st.qcount[Q_LAMBERTIAN], &st.qcount[Q_METALLIC],
                                &st.qcount[Q_DIELECTRIC], &st.qcount[Q_EMISSIVE]};
-  uint32_t *const datas[6] = {term, st.qdata[Q_CONNECT], st.qdata[Q_LAMBERTIAN], st.qdata[Q_METALLIC],
+  uint32_t *const datas[6] = {st.qdata[q0], st.qdata[Q_CONNECT], st.qdata[Q_LAMBERTIAN], st.qdata[Q_METALLIC],
                               st.qdata[Q_DIELECTRIC], st.qdata[Q_EMISSIVE]};
+  CamBasis cb;
+  if (RESPAWN) cb = cam_basis(fp.cam);
+  unsigned long long finished = 0, spawned = 0;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
@@ -236,6 +246,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
     uint32_t slot = 0;
     bool hit = false;
     uint32_t route = 0;  // queue of the hit material
+    float4 end_rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t end_src = kNoSample;
+    bool have_end = false;
     if (fin) {
       slot = ext[i];
       DPath *pp = st.path + slot;
@@ -255,7 +268,13 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
         a.x = a.x + b.x * sky;
         a.y = a.y + b.y * sky;
         a.z = a.z + b.z * sky;
-        p4[0] = a;
+        if (RESPAWN) {
+          end_rad = a;
+          end_src = __float_as_uint(b.w);
+          have_end = true;
+        } else {
+          p4[0] = a;
+        }
       } else {
         hit = true;
         best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
@@ -280,9 +299,38 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
           if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
         }
       }
+      if (RESPAWN && !hit && !have_end) {
+        end_rad = reinterpret_cast<const float4 *>(pp)[0];
+        end_src = reinterpret_cast<const uint32_t *>(pp)[7];
+      }
     }
-    const int r = !fin ? -1 : (!hit ? 0 : (int)(route - Q_CONNECT) + 1);
+    int r = !fin ? -1 : (!hit ? 0 : (int)(route - Q_CONNECT) + 1);
+    if (RESPAWN) {
+      const bool done = fin && !hit;
+      if (done) {
+        accumulate_sample(st, fp, end_src, end_rad);
+        finished++;
+      }
+      const unsigned long long si = block_reserve(shr, st.sample_index, done);
+      if (done && si < fp.sample_limit) {
+        spawn_sample(st, fp, cb, slot, si);
+        spawned++;
+      } else if (done) {
+        reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+        r = -1;
+      }
+    }
     block_push_n<6>(sh, counts, datas, r, slot);
+  }
+  if (RESPAWN) {
+    for (int off = 32; off > 0; off >>= 1) {
+      finished += __shfl_down(finished, off);
+      spawned += __shfl_down(spawned, off);
+    }
+    if (lane_id() == 0u) {
+      if (finished) atomicAdd(&st.stats[S_FINISHED], finished);
+      if (spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+    }
   }
 }
 
@@ -653,7 +701,8 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_extend_finish, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  if (fp.respawn) hipLaunchKernelGGL((k_extend_finish<true>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_extend_finish<false>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
