@@ -195,6 +195,12 @@ def main():
                             "scene that sits in L2 and Infinity Cache, so this exceeds what HBM could deliver; "
                             "traffic = measured memory-side bytes per launch",
                     "algorithmic_bytes_per_launch": per_launch, "launch_ms": ext_ms,
+                    # the stage that does bind: node fetches per second against the gather rate the
+                    # memory pipeline sustains for 32-B records of a table this size
+                    # (profiles/r01_gather_microbench.txt, 64 MB table, any occupancy)
+                    "node_steps_per_s": (counts.tlas_nodes + counts.blas_nodes) / max(st.extend_launches, 1) / (ext_ms * 1e-3)
+                    if ext_ms > 0 else 0.0,
+                    "gather_ceiling_per_s": 178.3e9,
                     "launches": int(st.extend_launches),
                     "per_ray": {"tlas_nodes": counts.tlas_nodes / max(counts.rays, 1),
                                 "instance_visits": counts.instance_visits / max(counts.rays, 1),
