@@ -360,6 +360,73 @@ def test_full_size_properties_per_material_path_1080p(pt, config_scenes):
     assert np.array_equal(a4[: 4 * 2048], w4) and np.array_equal(ac[:2048], wc)
 
 
+def test_full_size_properties_config4_thousand_instances_1080p(pt, config_scenes):
+    # configuration 4 at full size (1000 instances of the full-size dragon stand-in, teapot,
+    # suzanne and cube under one TLAS): ray-set parity on a sample, a slice of the render
+    # against the oracle, and the size-independent properties
+    arrays, info = config_scenes(4)
+    assert len(arrays["instances"]) == 1000
+    pt.upload_scene(arrays)
+    rays = random_rays(20000, 44, centre=(0.0, 0.0, 14.0), spread=9.0)
+    sc = po.Scene(arrays)
+    got, gc = pt.trace_closest(rays, want_counts=True)
+    want, wc = sc.trace_closest(rays, want_counts=True)
+    assert hits_equal(got, want)
+    assert (gc.tlas_nodes, gc.instance_visits, gc.blas_nodes, gc.triangles) == \
+           (wc.tlas_nodes, wc.instance_visits, wc.blas_nodes, wc.triangles)
+    W, H = info.width, info.height
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    pt.create_state(W, H, W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(2)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == 2) and st.finished_samples == 2 * W * H == st.spawned_samples
+    assert st.extend_rays - st.shade_events <= st.finished_samples
+    pt.create_state(W, H, 300007, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(1)
+    pt.render_spp(1)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+    oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    w4, wcnt, _ = sc.render(cam, src[:1024].copy(), W, H, oprm, 0, 2)
+    assert np.array_equal(a4[: 4 * 1024], w4) and np.array_equal(ac[:1024], wcnt)
+
+
+def test_full_size_properties_config5_4k(pt, config_scenes):
+    # configuration 5 at its own size, 3840x2160 (8.3 M sources), per-material shading with
+    # light sampling: every source gets its sample, slot count does not matter, a slice
+    # equals the oracle
+    arrays, info = config_scenes(5)
+    pt.upload_scene(arrays)
+    W, H = info.width, info.height
+    assert (W, H) == (3840, 2160)
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
+    pt.create_state(W, H, W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(1)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == 1) and st.finished_samples == W * H == st.spawned_samples
+    assert 0 < st.connect_rays <= st.shade_events <= st.extend_rays
+    pt.create_state(W, H, 1000003, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(1)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+    sc = po.Scene(arrays)
+    oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
+    w4, wc, _ = sc.render(cam, src[:1024].copy(), W, H, oprm, 0, 1)
+    assert np.array_equal(a4[: 4 * 1024], w4) and np.array_equal(ac[:1024], wc)
+
+
 def test_plain_c_driver_renders_the_same_sums(pt, config_scenes, tmp_path):
     # examples/render_c.c (built by `make examples`) goes through both C ABIs from
     # C: its checksum of the radiance sums must equal this process's render
