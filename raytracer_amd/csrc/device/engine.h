@@ -33,7 +33,7 @@
 namespace mirt {
 
 #ifndef MIRT_REFILL_BELOW
-#define MIRT_REFILL_BELOW 40
+#define MIRT_REFILL_BELOW 56
 #endif
 constexpr uint32_t kCoopLeaf = kScanLeafMin;  // leaves this big go to the whole wave (they have scan blocks)
 constexpr int kRefillBelow = MIRT_REFILL_BELOW;  // refill when fewer lanes than this are walking
