@@ -86,8 +86,8 @@ constexpr uint32_t kBigNode = MIRT_BUILD_BIG;   // nodes this big get a 1024-thr
 #define MIRT_BUILD_TINY 16u
 #endif
 constexpr uint32_t kTinyNode = MIRT_BUILD_TINY;  // nodes up to this size are split by one thread each, with the loop as written
-constexpr uint32_t kHugeNode = 16384u; // nodes this big are split by many blocks, kChunk elements each
-constexpr uint32_t kChunk = 4096u;     // four elements per thread of a 1024-thread block
+constexpr uint32_t kHugeNode = 16384u; // nodes this big are split by many blocks, kBuildChunk elements each
+constexpr uint32_t kBuildChunk = 4096u;     // four elements per thread of a 1024-thread block
 
 // A node that many blocks split together: what they share between kernels.
 struct HugeNode {
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_build_prep(BuildBufs bb) {
 }
 
 // the root: a leaf over every face (src/blas.rs:64-71) with its box; the box keys of
-// kChunk faces per block meet in root_keys (all ones before the launch)
+// kBuildChunk faces per block meet in root_keys (all ones before the launch)
 __global__ __launch_bounds__(1024) void k_build_root_keys(BuildBufs bb, unsigned long long *root_keys) {
   __shared__ BlockTmp<1024> sh;
   unsigned long long k[6];
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_build_root_keys(BuildBufs bb, unsigned
   for (int q = 0; q < 6; ++q) k[q] = ~0ull;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t p = blockIdx.x * kChunk + (uint32_t)j * 1024u + threadIdx.x;
+    const uint32_t p = blockIdx.x * kBuildChunk + (uint32_t)j * 1024u + threadIdx.x;
     if (p >= bb.nf) continue;
     const float4 mn = bb.bmn[p], mx = bb.bmx[p];  // the order is still the identity
     const float vmn[3] = {mn.x, mn.y, mn.z}, vmx[3] = {mx.x, mx.y, mx.z};
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_build_split_tiny(BuildBufs bb, uint32_t
 // ---------------------------------------------------------------- huge nodes
 // A node of kHugeNode elements or more would keep one block — one CU — busy for
 // milliseconds, so the few such nodes of a level are split by all blocks
-// together, kChunk elements per block, in a sequence of short kernels that
+// together, kBuildChunk elements per block, in a sequence of short kernels that
 // meet in the node's HugeNode record.  The arithmetic is that of k_build_split.
 
 __device__ __forceinline__ float key_to_float(uint32_t k) {  // inverse of ord_key (a zero comes back as +0)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_huge_list(BuildBufs bb, uint32_t first
       h.axis = (uint32_t)split_axis(node);
       h.kmin = 0xFFFFFFFFu;
       h.kmax = 0u;
-      h.n_chunks = (n + kChunk - 1u) / kChunk;
+      h.n_chunks = (n + kBuildChunk - 1u) / kBuildChunk;
       for (int q = 0; q < 12; ++q) h.bk[q] = ~0ull;
       bb.huge[b] = h;
     }
@@ -582,8 +582,8 @@ __device__ __forceinline__ bool chunk_ref(const BuildBufs &bb, ChunkRef &c) {
   c.s = h.s;
   c.n = h.n;
   c.axis = h.axis;
-  c.lo = (blockIdx.x - h.chunk0) * kChunk;
-  c.hi = c.lo + kChunk < h.n ? c.lo + kChunk : h.n;
+  c.lo = (blockIdx.x - h.chunk0) * kBuildChunk;
+  c.hi = c.lo + kBuildChunk < h.n ? c.lo + kBuildChunk : h.n;
   return true;
 }
 __device__ __forceinline__ float chunk_centroid(const BuildBufs &bb, const ChunkRef &c, uint32_t p) {
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void k_huge_scan(BuildBufs bb) {
   uint32_t run = 0u;
   for (uint32_t c = 0; c < h.n_chunks; ++c) {
     const uint32_t r = bb.chunk_r[h.chunk0 + c];
-    const uint32_t size = (c + 1u) * kChunk <= h.n ? kChunk : h.n - c * kChunk;
+    const uint32_t size = (c + 1u) * kBuildChunk <= h.n ? kBuildChunk : h.n - c * kBuildChunk;
     bb.chunk_r[h.chunk0 + c] = run;
     bb.chunk_lb[h.chunk0 + c] = size - r;  // L's in the chunk, for the pass below
     run += r;
@@ -869,7 +869,7 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
   unsigned long long *root_keys = nullptr;
   const size_t cap = 2 * (size_t)n_faces;  // a split adds two nodes and there are fewer than n_faces splits
   // a level holds at most n_faces / kHugeNode huge nodes, and their chunks are full but for one per node
-  const size_t max_huge = n_faces / kHugeNode + 1, max_chunks = n_faces / kChunk + max_huge + 1;
+  const size_t max_huge = n_faces / kHugeNode + 1, max_chunks = n_faces / kBuildChunk + max_huge + 1;
   // one workspace, kept by the caller between builds and grown when a mesh needs more
   auto carve = [&](unsigned char *base) {
     Carver c{base};
@@ -926,7 +926,7 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
   const unsigned fblocks = (n_faces + 255u) / 256u;
   hipLaunchKernelGGL(k_build_prep, dim3(fblocks), dim3(256), 0, stream, bb);
   BUILD_TRY(hipMemsetAsync(root_keys, 0xFF, 6 * sizeof(unsigned long long), stream));
-  hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kChunk - 1u) / kChunk), dim3(1024), 0, stream, bb, root_keys);
+  hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kBuildChunk - 1u) / kBuildChunk), dim3(1024), 0, stream, bb, root_keys);
   hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, stream, bb, root_keys);
 
   // grow the tree one level at a time; a level is the run of nodes the previous one created
