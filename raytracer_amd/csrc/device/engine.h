@@ -136,7 +136,10 @@ struct RayIn {
 
 // Work distribution: every wave grabs chunks of kChunk consecutive queue
 // entries with one atomic per chunk and hands them to its lanes as they free up.
-constexpr uint32_t kChunk = 128u;
+#ifndef MIRT_WORK_CHUNK
+#define MIRT_WORK_CHUNK 128u
+#endif
+constexpr uint32_t kChunk = MIRT_WORK_CHUNK;
 struct WorkSource {
   uint32_t *counter;  // zeroed before the launch
   uint32_t count;     // number of queue entries
