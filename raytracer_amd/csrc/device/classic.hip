@@ -36,22 +36,49 @@ struct SlotIn {
   uint32_t inst, ff;
 };
 
-__device__ __forceinline__ void load_slot(const DState &st, uint32_t slot, SlotIn &s) {
+// RAW: the hit record still holds what the traversal left (u, v, t, instance;
+// triangle in the last word) and the world-space record of extensionMain
+// (shaders/ray_extend.slang:34-50, 204-207) is built here; so is the bounce
+// count of archive/extension.slang:94-101 — a hit costs one bounce, and a path
+// out of bounces ends without being shaded: the function then returns false
+// with only s.pa loaded.
+template <bool RAW>
+__device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, uint32_t slot, SlotIn &s) {
   const float4 *p4 = reinterpret_cast<const float4 *>(st.path + slot);
   s.pa = p4[0];
+  if (RAW) {
+    const uint32_t bounces = __float_as_uint(s.pa.w) - 1u;
+    s.pa.w = __uint_as_float(bounces);
+    if (bounces == 0u) return false;
+  }
   s.pb = p4[1];
   s.rng = load_rng(st.path + slot);
   v3 rpos;
   uint32_t li, lp;
   load_ray(st.ray, slot, rpos, s.rdir, li, lp);
   const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
-  const float4 ha = h4[0], hb = h4[1];
-  const uint32_t inst_ff = __float_as_uint(ha.w);
-  s.inst = inst_ff & 0x7FFFFFFFu;
-  s.ff = inst_ff >> 31;
-  s.hpos = V3(ha.x, ha.y, ha.z);
+  v3 hn;
+  if (RAW) {
+    const float4 raw = h4[0];
+    BestHit best;
+    best.u = raw.x;
+    best.v = raw.y;
+    best.t = raw.z;
+    best.inst = __float_as_uint(raw.w);
+    best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
+    finish_hit(sc, s.rdir, best, s.hpos, hn, s.ff);
+    s.inst = best.inst;
+  } else {
+    const float4 ha = h4[0], hb = h4[1];
+    const uint32_t inst_ff = __float_as_uint(ha.w);
+    s.inst = inst_ff & 0x7FFFFFFFu;
+    s.ff = inst_ff >> 31;
+    s.hpos = V3(ha.x, ha.y, ha.z);
+    hn = V3(hb.x, hb.y, hb.z);
+  }
   const float sgn = s.ff != 0u ? 1.0f : -1.0f;
-  s.hn = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
+  s.hn = V3(hn.x * sgn, hn.y * sgn, hn.z * sgn);
+  return true;
 }
 
 __device__ __forceinline__ void store_slot(const DState &st, uint32_t slot, const SlotIn &s, v3 new_pos, v3 new_dir) {
@@ -199,14 +226,15 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
 // ------------------------------------------------------- material kernels
 // Common frame of the four kernels: pop `queue`, shade, push to the next
 // frame's extension queue (alive) or terminate queue.
-template <int KIND>
+template <int KIND, bool RAW>
 __global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const int q = Q_LAMBERTIAN - 1 + KIND;
   const uint32_t *mq = st.qdata[q];
   const uint32_t count = st.qcount[q];
-  const bool use_shadow = fp.p.nee != 0u && fp.have_lights != 0u;
+  const bool use_shadow = !RAW;  // light sampling on: the connect kernel ran and left ShadowData
+  unsigned long long unshaded = 0;  // entries that were out of bounces (RAW only)
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
@@ -215,7 +243,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st,
     if (active) {
       slot = mq[i];
       SlotIn s;
-      load_slot(st, slot, s);
+      if (!load_slot<RAW>(sc, st, slot, s)) {
+        reinterpret_cast<float4 *>(st.path + slot)[0] = s.pa;  // out of bounces: the path ends unshaded
+        unshaded++;
+      } else {
       const DInst *inst = &sc.inst[s.inst];
       v3 new_pos = s.hpos, new_dir = s.rdir;
       v3 thr = V3(s.pb.x, s.pb.y, s.pb.z), rad = V3(s.pa.x, s.pa.y, s.pa.z);
@@ -317,11 +348,16 @@ __global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st,
       s.pa.x = rad.x; s.pa.y = rad.y; s.pa.z = rad.z;
       s.pb.x = thr.x; s.pb.y = thr.y; s.pb.z = thr.z;
       store_slot(st, slot, s, new_pos, new_dir);
+      }
     }
     block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
                 &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)count);
+  if (RAW) {
+    for (int off = 32; off > 0; off >>= 1) unshaded += __shfl_down(unshaded, off);
+    if (lane_id() == 0u && unshaded) atomicAdd(&st.stats[S_SHADE_EVENTS], 0ull - unshaded);
+  }
 }
 
 }  // namespace
@@ -336,10 +372,19 @@ void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, co
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   // the four per-material kernels, one queue each (archive frame order:
   // src/app.rs:402-410 dispatches every material phase each frame)
-  hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  const dim3 grid(cfg.grid_blocks), block(kStreamBlock);
+  if (fp.p.nee && fp.have_lights) {
+    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, false>), grid, block, 0, cfg.stream, sc, st, fp);
+  } else {
+    // no connect kernel: the material kernels build the hit record from the traversal's raw result
+    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, true>), grid, block, 0, cfg.stream, sc, st, fp);
+  }
 }
 
 }  // namespace mirt

@@ -221,7 +221,10 @@ __global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, D
 // accumulated and its slot takes the next sample at once, as in
 // k_finish_shade_uber<true>; paths that end in a material kernel still go
 // through the terminate queue and the sample kernel.
-template <bool RESPAWN>
+// RAW (no light sampling): the material kernel is the only reader of the hit
+// record, so it builds the world-space record itself from u, v, t, instance and
+// triangle (finish_hit) and counts the bounce; this kernel only routes.
+template <bool RESPAWN, bool RAW>
 __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
@@ -277,26 +280,28 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
         }
       } else {
         hit = true;
-        best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
-        const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
-        const float4 ra = r4[0], rb = r4[1];
-        v3 hp, hn;
-        uint32_t ff;
-        finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
-        h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
-        h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
-        // archive/extension.slang:94-101: a hit costs one bounce; out of
-        // bounces means terminate without shading
-        uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
-        const uint32_t bounces = *pb - 1u;
-        *pb = bounces;
-        if (bounces == 0u) {
-          hit = false;
-        } else if (fp.p.nee && fp.have_lights) {
-          route = Q_CONNECT;
-        } else {
+        if (!RAW) {
+          best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
+          const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
+          const float4 ra = r4[0], rb = r4[1];
+          v3 hp, hn;
+          uint32_t ff;
+          finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
+          h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
+          h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
+        }
+        if (RAW) {
+          // the material kernel counts the bounce; here the slot only finds its queue
           route = Q_LAMBERTIAN - 1u + sc.inst[best.inst].kind;
           if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
+        } else {
+          // archive/extension.slang:94-101: a hit costs one bounce; out of
+          // bounces means terminate without shading
+          uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
+          const uint32_t bounces = *pb - 1u;
+          *pb = bounces;
+          if (bounces == 0u) hit = false;
+          else route = Q_CONNECT;
         }
       }
       if (RESPAWN && !hit && !have_end) {
@@ -701,8 +706,15 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  if (fp.respawn) hipLaunchKernelGGL((k_extend_finish<true>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_extend_finish<false>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  const bool raw = !(fp.p.nee && fp.have_lights);  // the connect kernel needs the world-space record
+  const dim3 grid(cfg.grid_blocks), block(kStreamBlock);
+  if (fp.respawn) {
+    if (raw) hipLaunchKernelGGL((k_extend_finish<true, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend_finish<true, false>), grid, block, 0, cfg.stream, sc, st, fp);
+  } else {
+    if (raw) hipLaunchKernelGGL((k_extend_finish<false, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend_finish<false, false>), grid, block, 0, cfg.stream, sc, st, fp);
+  }
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
