@@ -90,6 +90,33 @@ def test_one_sided_partitions_and_equal_centroids(pt):
     assert_same_blas(pt, "grid", positions, indices)
 
 
+def test_random_meshes_of_many_shapes(pt):
+    # eighty seeded meshes: sizes from 5 to 60 000 faces, vertex clouds that are uniform, clustered,
+    # flat, sorted along an axis or quantised to a coarse grid (many equal centroids and boxes),
+    # with and without runs of duplicated faces
+    rng = np.random.default_rng(2026)
+    for case in range(80):
+        n_faces = int(rng.choice([5, 9, 17, 33, 100, 511, 513, 3000, 20000, 60000]) + rng.integers(0, 7))
+        n_vertices = max(4, int(n_faces * rng.choice([0.02, 0.5, 1.5])))
+        kind = case % 5
+        xyz = rng.uniform(-1.0, 1.0, (n_vertices, 3))
+        if kind == 1:
+            xyz = rng.normal(size=(n_vertices, 3)) * 0.01 + rng.integers(-2, 3, (n_vertices, 1))
+        elif kind == 2:
+            xyz[:, rng.integers(0, 3)] = 0.25
+        elif kind == 3:
+            xyz = xyz[np.argsort(xyz[:, 0])]
+        elif kind == 4:
+            xyz = np.round(xyz * 4.0) / 4.0
+        indices = rng.integers(0, n_vertices, (n_faces, 3))
+        if kind == 3:
+            indices = np.sort(indices, axis=0)  # faces roughly ordered along x
+        if case % 3 == 0 and n_faces > 20:
+            a = int(rng.integers(0, n_faces // 2))
+            indices[a:a + n_faces // 3] = indices[a]
+        assert_same_blas(pt, f"random{case}", xyz.astype("<f4"), indices.astype("<u4").reshape(-1))
+
+
 def test_signed_zero_bounds_follow_the_first_occurrence(pt):
     # coordinates that are +0 or -0 at random: the sign of a zero bound is that of the first
     # element in order, as the host's sequential fold keeps it — in leaves and in inner nodes
