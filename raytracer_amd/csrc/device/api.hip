@@ -871,9 +871,12 @@ int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
   int rc = check_ready(ctx);
   if (rc != MIRT_OK) return rc;
   if (spp == 0) return MIRT_OK;
-  if ((rc = seed_slots(ctx)) != MIRT_OK) return rc;  // drops paths left by mirt_step
   const unsigned long long limit = (unsigned long long)ctx->st.n_sources * spp;
   const uint32_t first = ctx->next_sample;
+  // paths left by mirt_step are dropped: every slot starts on a sample of this call
+  ctx->frame = 0;
+  ctx->slots_seeded = true;
+  launch_spawn_first(launch_cfg(ctx), ctx->st, frame_params(ctx, limit, first));
   if ((rc = fetch_counters(ctx)) != MIRT_OK) return rc;
   const unsigned long long finished0 = ctx->h_stats[S_FINISHED];
   // Each frame advances every path by one bounce.  Poll the finished-sample

@@ -84,6 +84,8 @@ void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &
 // dst[i] += src[i] for n words (the integer accumulators of another context)
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n);
 void launch_init_slots(const LaunchCfg &cfg, const DState &st);
+// frame 0 of a render call: the first min(slots, sample_limit) samples spawned into slots 0.. (no terminate queue pass)
+void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
 
 // `work` is a zeroed device word (the launch's chunk cursor).
 void launch_trace(const LaunchCfg &cfg, const DScene &sc, const DRay *rays, const float *tmax, size_t n,

@@ -175,6 +175,24 @@ __global__ __launch_bounds__(256) void k_init_slots(DState st) {
   if (i < QW_COUNT) st.qcount[i] = i == Q_TERM0 ? st.slots : 0u;
 }
 
+// The start of a render call: slot i takes sample i of the call (as many as the
+// call has samples for) and goes straight onto frame 0's extension queue, entry
+// i = slot i.  Replaces k_init_slots plus the first pass of the sample kernel
+// over a terminate queue that would list every slot.
+__global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t n = fp.sample_limit < (unsigned long long)st.slots ? (uint32_t)fp.sample_limit : st.slots;
+  if (i < n) {
+    spawn_sample(st, fp, cam_basis(fp.cam), i, (unsigned long long)i);
+    st.qdata[Q_EXT0][i] = i;
+  }
+  if (i < QW_COUNT) st.qcount[i] = i == Q_EXT0 ? n : 0u;
+  if (i == 0u) {
+    *st.sample_index = n;
+    atomicAdd(&st.stats[S_SPAWNED], (unsigned long long)n);
+  }
+}
+
 // ---------------------------------------------------------------- extend
 
 // The closest-hit walk of extensionMain (shaders/ray_extend.slang:12-33) for
@@ -674,6 +692,11 @@ __global__ void k_math_selftest(const float *a, const float *b, const float *c, 
 void launch_init_slots(const LaunchCfg &cfg, const DState &st) {
   const uint32_t n = st.slots > (uint32_t)QW_COUNT ? st.slots : (uint32_t)QW_COUNT;
   hipLaunchKernelGGL(k_init_slots, dim3((n + 255u) / 256u), dim3(256), 0, cfg.stream, st);
+}
+
+void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {
+  const uint32_t n = st.slots > (uint32_t)QW_COUNT ? st.slots : (uint32_t)QW_COUNT;
+  hipLaunchKernelGGL(k_spawn_first, dim3((n + 255u) / 256u), dim3(256), 0, cfg.stream, st, fp);
 }
 
 void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
