@@ -9,6 +9,9 @@
  * With `members` > 1 the same render goes through a group of that many contexts
  * (MIRT_GROUP_DEVICES="0,1,..." names their devices; default: all on device 0),
  * which split the samples and add their accumulators up; the output is the same.
+ * With MIRT_DEVICE_BUILD=1 in the environment the meshes' BLASes are built on
+ * device 0 (mirt_build_blas behind the host model's builder callback) instead of
+ * on the host; the output is the same again.
  *
  * Prints "checksum <sum of all fixed-point radiance sums> samples <n>". */
 #include <stdint.h>
@@ -27,6 +30,12 @@
     }                                                                           \
   } while (0)
 
+/* mirt_build_blas as the host model's BLAS builder */
+static int build_on_device(void *ctx, const float *positions4, uint32_t n_positions, uint32_t *faces4,
+                           uint32_t n_faces, MirtBVHNode *nodes, uint32_t capacity, uint32_t *n_nodes) {
+  return mirt_build_blas((mirt_ctx *)ctx, positions4, n_positions, faces4, n_faces, nodes, capacity, n_nodes, NULL);
+}
+
 int main(int argc, char **argv) {
   if (argc < 5) {
     fprintf(stderr, "usage: %s <asset_dir> <config 1..5> <spp> <out.ppm> [width height [members]]\n", argv[0]);
@@ -39,6 +48,12 @@ int main(int argc, char **argv) {
   /* host side: scene graph -> flat buffers (MeshServer / BLAS / TLAS / binder) */
   mirth_scene *scene = mirth_scene_new();
   MirthConfigInfo info;
+  mirt_ctx *build_ctx = NULL;
+  const char *device_build = getenv("MIRT_DEVICE_BUILD");
+  if (device_build && atoi(device_build) != 0) {
+    CHECK(build_ctx, mirt_create(0, &build_ctx));
+    mirth_set_blas_builder(scene, build_on_device, build_ctx);
+  }
   if (mirth_build_config(scene, config, asset_dir, 0, 0, &info) != 0 || mirth_bind(scene) != 0) {
     fprintf(stderr, "scene: %s\n", mirth_last_error(scene));
     return 1;
@@ -126,6 +141,7 @@ int main(int argc, char **argv) {
 
   if (grp) mirt_group_destroy(grp);
   else mirt_destroy(ctx);
+  if (build_ctx) mirt_destroy(build_ctx);
   mirth_scene_free(scene);
   free(sources);
   free(rgb);

@@ -456,6 +456,12 @@ def test_plain_c_driver_renders_the_same_sums(pt, config_scenes, tmp_path):
     assert out2.returncode == 0, out2.stderr
     assert out2.stdout.split() == words
     assert open(tmp_path / "g.ppm", "rb").read() == ppm
+    # and with the BLASes built on the device through the host model's builder callback
+    out3 = subprocess.run([exe, assets, "1", str(spp), str(tmp_path / "d.ppm"), str(W), str(H)], capture_output=True,
+                          text=True, timeout=100, env=dict(os.environ, MIRT_DEVICE_BUILD="1"))
+    assert out3.returncode == 0, out3.stderr
+    assert out3.stdout.split() == words
+    assert open(tmp_path / "d.ppm", "rb").read() == ppm
 
 
 def _three_suzannes(moved):
