@@ -327,6 +327,33 @@ def test_full_size_properties_config3_1080p(pt, config_scenes):
     assert np.all(fc == 1) and np.all(f4.reshape(-1, 4)[:, :3] == 10000)
 
 
+def test_config3_at_its_full_sample_count(pt, config_scenes):
+    # the headline configuration at its own size: 1920x1080, 256 samples per pixel, 8 bounces.
+    # One call of 256 spp equals four calls of 64 with another number of slots, every source
+    # gets exactly 256 samples, and no fixed-point sum comes near the 32-bit range
+    arrays, info = config_scenes(3)
+    assert info.spp == 256
+    pt.upload_scene(arrays)
+    W, H = info.width, info.height
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed)
+    pt.create_state(W, H, 16 * W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(256)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == 256) and st.finished_samples == 256 * W * H == st.spawned_samples
+    assert int(a4.max()) < 2 ** 31
+    pt.create_state(W, H, 24 * W * H + 17, src, prm)
+    pt.set_camera(cam)
+    for _ in range(4):
+        pt.render_spp(64)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+
+
 def test_full_size_properties_per_material_path_1080p(pt, config_scenes):
     # configuration 5's scene with the full-size dragon, per-material shading with
     # light sampling, at 1080p: properties that need no full oracle run
