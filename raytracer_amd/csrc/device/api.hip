@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <memory>
 #include <new>
 #include <algorithm>
 #include <string>
@@ -501,9 +502,11 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   ctx->geom_tri_base.assign(d->n_geometries, 0);
   ctx->geom_root_start.assign(d->n_geometries, 0);
   ctx->geom_root_count.assign(d->n_geometries, 0);
+  // Host staging is written exactly once: the big arrays are left uninitialised
+  // (value-initialising 150 MB costs more than packing it) and the triangles are
+  // packed straight into the geometry buffer once its layout is known.
   std::vector<DNode> nodes;
-  std::vector<DTri> tris(d->n_indices);
-  std::vector<DTriN> trins(d->n_indices);
+  std::unique_ptr<DTriN[]> trins(new DTriN[d->n_indices ? d->n_indices : 1]);
   struct ScanLeaf {
     uint32_t first_tri, count;
     size_t block;
@@ -511,6 +514,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   };
   std::vector<ScanLeaf> scan_leaves;
   size_t scan_blocks = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> big_sizes;  // first triangle of a leaf with an out-of-line size, the size
   // room for the TLAS to grow without moving the BLAS blocks
   ctx->tlas_capacity = d->n_tlas_nodes + d->n_tlas_nodes / 2u + 16u;
   nodes.reserve((size_t)ctx->tlas_capacity + d->n_blas_nodes + 2 * d->n_geometries + 3);
@@ -521,8 +525,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     const MirtGeometryOffsets &o = d->geometry_offsets[g];
     const bool last = g + 1 == d->n_geometries;
     const uint32_t node_end = last ? d->n_blas_nodes : d->geometry_offsets[g + 1].blas_node;
-    const uint32_t idx_end = last ? d->n_indices : d->geometry_offsets[g + 1].index;
-    const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index;
+    const uint32_t nn = node_end - o.blas_node;
     if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
     ctx->geom_node_base[g] = (uint32_t)nodes.size();
     ctx->geom_tri_base[g] = o.index;
@@ -535,27 +538,12 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     nodes.resize(at + nn);
     std::vector<uint32_t> sizes(nn);
     pack_nodes(d->blas_nodes + o.blas_node, nn, nodes.data() + at, sizes.data(), false);
-    for (uint32_t p = 0; p < ni; ++p) {
-      const MirtIndex &f = d->indices[o.index + p];
-      const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
-      const MirtVertex &v1 = d->vertices[o.vertex + f.v[1]];
-      const MirtVertex &v2 = d->vertices[o.vertex + f.v[2]];
-      DTri t;
-      memset(&t, 0, sizeof(t));
-      t.p0x = v0.position[0]; t.p0y = v0.position[1]; t.p0z = v0.position[2];
-      t.e1x = v1.position[0] - v0.position[0]; t.e1y = v1.position[1] - v0.position[1]; t.e1z = v1.position[2] - v0.position[2];
-      t.e2x = v2.position[0] - v0.position[0]; t.e2y = v2.position[1] - v0.position[1]; t.e2z = v2.position[2] - v0.position[2];
-      tris[o.index + p] = t;
-      DTriN n;
-      memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
-      trins[o.index + p] = n;
-    }
-    // out-of-line leaf sizes ride in the first triangle of the leaf; leaves the
-    // whole wave scans get a second, lane-interleaved copy of their triangles
+    // leaves the whole wave scans get a second, lane-interleaved copy of their triangles;
+    // out-of-line leaf sizes ride in the first triangle of the leaf (written below)
     for (uint32_t i = 0; i < nn; ++i) {
       const DNode &dn = nodes[at + i];
       const uint32_t tag = dn.b >> 24;
-      if (tag == kBigLeaf && sizes[i] > 0) tris[o.index + dn.a].p0w = sizes[i];
+      if (tag == kBigLeaf && sizes[i] > 0) big_sizes.push_back({o.index + dn.a, sizes[i]});
       if (tag >= kScanLeafMin) {
         const uint32_t cnt = tag == kBigLeaf ? sizes[i] : tag;
         scan_leaves.push_back(ScanLeaf{o.index + dn.a, cnt, scan_blocks, o.vertex});
@@ -566,11 +554,36 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   if ((nodes.size() & 1u) == 0u) nodes.push_back(DNode{});
   const size_t node_bytes = nodes.size() * sizeof(DNode);
   const size_t tri_off = (node_bytes + 255u) & ~(size_t)255u;
-  const size_t scan_off = (tri_off + tris.size() * sizeof(DTri) + 64u + 255u) & ~(size_t)255u;
+  const size_t scan_off = (tri_off + (size_t)d->n_indices * sizeof(DTri) + 64u + 255u) & ~(size_t)255u;
   const size_t geo_bytes = scan_off + scan_blocks * (size_t)kScanBlockBytes + 64u;  // tail pad: 16-byte reads past the last record stay inside
   if (geo_bytes >= ((size_t)1 << 32))
     return fail(ctx, MIRT_ERR_BAD_SCENE, "nodes and triangles exceed the 4 GiB the traversal kernels address");
-  std::vector<unsigned char> geo(geo_bytes, 0);
+  std::unique_ptr<unsigned char[]> geo(new unsigned char[geo_bytes]);
+  memcpy(geo.get(), nodes.data(), node_bytes);
+  memset(geo.get() + node_bytes, 0, tri_off - node_bytes);
+  const size_t tri_end = tri_off + (size_t)d->n_indices * sizeof(DTri);
+  memset(geo.get() + tri_end, 0, geo_bytes - tri_end);  // pads and the scan blocks' unused lanes
+  DTri *tris = reinterpret_cast<DTri *>(geo.get() + tri_off);
+  for (uint32_t g = 0; g < d->n_geometries; ++g) {
+    const MirtGeometryOffsets &o = d->geometry_offsets[g];
+    const uint32_t idx_end = g + 1 == d->n_geometries ? d->n_indices : d->geometry_offsets[g + 1].index;
+    for (uint32_t p = o.index; p < idx_end; ++p) {
+      const MirtIndex &f = d->indices[p];
+      const MirtVertex &v0 = d->vertices[o.vertex + f.v[0]];
+      const MirtVertex &v1 = d->vertices[o.vertex + f.v[1]];
+      const MirtVertex &v2 = d->vertices[o.vertex + f.v[2]];
+      DTri t;
+      memset(&t, 0, sizeof(t));
+      t.p0x = v0.position[0]; t.p0y = v0.position[1]; t.p0z = v0.position[2];
+      t.e1x = v1.position[0] - v0.position[0]; t.e1y = v1.position[1] - v0.position[1]; t.e1z = v1.position[2] - v0.position[2];
+      t.e2x = v2.position[0] - v0.position[0]; t.e2y = v2.position[1] - v0.position[1]; t.e2z = v2.position[2] - v0.position[2];
+      tris[p] = t;
+      DTriN n;
+      memcpy(n.n0, v0.normal, 16); memcpy(n.n1, v1.normal, 16); memcpy(n.n2, v2.normal, 16);
+      trins[p] = n;
+    }
+  }
+  for (const auto &bs : big_sizes) tris[bs.first].p0w = bs.second;
   // Scan blocks: 64 triangles each, as three planes a wave reads with one
   // contiguous load each — plane 0 (p0.xyz, e1.x) and plane 1 (e1.yz, e2.xy)
   // 16 bytes per lane, plane 2 (e2.z) 4 bytes per lane.  The byte offset of a
@@ -580,7 +593,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     tris[sl.first_tri].e1w = (uint32_t)first;
     for (uint32_t k = 0; k < sl.count; ++k) {
       const DTri &t = tris[sl.first_tri + k];
-      unsigned char *blk = geo.data() + first + (k / 64u) * (size_t)kScanBlockBytes;
+      unsigned char *blk = geo.get() + first + (k / 64u) * (size_t)kScanBlockBytes;
       const uint32_t lane = k % 64u;
       const float plane0[4] = {t.p0x, t.p0y, t.p0z, t.e1x}, plane1[4] = {t.e1y, t.e1z, t.e2x, t.e2y};
       memcpy(blk + lane * 16u, plane0, 16);
@@ -637,11 +650,10 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       }
     }
   }
-  memcpy(geo.data(), nodes.data(), node_bytes);
-  if (!tris.empty()) memcpy(geo.data() + tri_off, tris.data(), tris.size() * sizeof(DTri));
-  const unsigned char *pg = nullptr;
-  int rc = dev_upload(ctx, ctx->scene_allocs, &pg, geo);
+  unsigned char *pg = nullptr;
+  int rc = dev_alloc(ctx, ctx->scene_allocs, &pg, geo_bytes);
   if (rc != MIRT_OK) return rc;
+  HIP_TRY(ctx, hipMemcpy(pg, geo.get(), geo_bytes, hipMemcpyHostToDevice));
   sc.geo = pg;
   sc.geo_bytes = (uint32_t)geo_bytes;
   sc.tri_off = (uint32_t)tri_off;
@@ -650,7 +662,11 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   sc.leaf_cache = nullptr;
   sc.leaf_cache_bytes = (uint32_t)(cache_image.size() * 16u);
   if (!cache_image.empty() && (rc = dev_upload(ctx, ctx->scene_allocs, &sc.leaf_cache, cache_image)) != MIRT_OK) return rc;
-  return dev_upload(ctx, ctx->scene_allocs, &sc.trin, trins);
+  DTriN *ptn = nullptr;
+  if ((rc = dev_alloc(ctx, ctx->scene_allocs, &ptn, d->n_indices)) != MIRT_OK) return rc;
+  if (d->n_indices) HIP_TRY(ctx, hipMemcpy(ptn, trins.get(), (size_t)d->n_indices * sizeof(DTriN), hipMemcpyHostToDevice));
+  sc.trin = ptn;
+  return MIRT_OK;
 }
 
 // Everything that depends on instances, transforms or materials: the TLAS
