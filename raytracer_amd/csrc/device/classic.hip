@@ -226,8 +226,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
 // ------------------------------------------------------- material kernels
 // Common frame of the four kernels: pop `queue`, shade, push to the next
 // frame's extension queue (alive) or terminate queue.
+#ifndef MIRT_MATERIAL_WAVES
+#define MIRT_MATERIAL_WAVES 4
+#endif
 template <int KIND, bool RAW>
-__global__ __launch_bounds__(kStreamBlock) void k_material(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const int q = Q_LAMBERTIAN - 1 + KIND;
