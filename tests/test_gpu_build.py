@@ -165,3 +165,17 @@ def test_bad_arguments_are_refused(pt):
         pt.build_blas(pos, faces)
     faces, nodes, _ = pt.build_blas(pos, np.zeros((0, 4), "<u4"))  # the empty mesh keeps its root leaf
     assert len(nodes) == 1 and nodes[0]["is_leaf"] == 1 and len(faces) == 0
+    # too little room for the nodes: refused, with the count that is needed, and the call works again after
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    xyz, indices = soup(rng, 60, 100)
+    p4, f0 = positions4(xyz), faces_of(indices)
+    want_faces, want_nodes = host.build_blas(p4, f0)
+    small = np.zeros(3, ffi.BVHNode)
+    f1 = f0.copy()
+    n = C.c_uint32()
+    rc = pt._L.mirt_build_blas(pt._h, p4.ctypes.data, len(p4), f1.ctypes.data, len(f1), small.ctypes.data, len(small),
+                               C.byref(n), None)
+    assert rc != 0 and n.value == len(want_nodes) and np.array_equal(f1, f0)  # the faces were left alone
+    faces, nodes, _ = pt.build_blas(p4, f0)
+    assert np.array_equal(faces, want_faces) and nodes.tobytes() == want_nodes.tobytes()
