@@ -150,6 +150,152 @@ def test_standalone_host_builder_and_builder_callback():
     s.close()
 
 
+# ------------------------------------------- second restatement, in numpy
+def _f32(x):
+    return np.float32(x)
+
+
+def _fma(a, b, c):
+    """round_f32(a * b + c) with the product and the sum exact (rationals)."""
+    from fractions import Fraction
+    return np.float32(float(Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))))
+
+
+def _dot3(a, b):  # the arithmetic contract: fma(az, bz, fma(ay, by, ax * bx))
+    return _fma(a[2], b[2], _fma(a[1], b[1], _f32(a[0]) * _f32(b[0])))
+
+
+def _cross3(a, b):  # cross.x = fma(ay, bz, -(az * by)), ...
+    return [_fma(a[1], b[2], -(_f32(a[2]) * _f32(b[1]))), _fma(a[2], b[0], -(_f32(a[0]) * _f32(b[2]))),
+            _fma(a[0], b[1], -(_f32(a[1]) * _f32(b[0])))]
+
+
+def test_camera_rays_against_a_numpy_restatement_of_the_shader_text():
+    # spawnSample (shaders/sample.slang:86-98) written a second time, in numpy float32 scalars from
+    # the shader text and the arithmetic contract, against the C oracle's camera rays
+    arrays, info = host.build_config_scene(1)
+    W, H = 48, 32
+    src = host.make_sample_sources(W, H, 77)
+    cam = host.default_camera(W, H)
+    cam["position"][0] = (0.25, -0.5, 0.125)
+    cam["focal_length"] = 1.5
+    prm = po.default_params(max_bounces=4, seed=0xABCDEF)
+    sc = po.Scene(arrays)
+    for sample_no in (0, 5):
+        rays = sc.bounce_rays(cam, src, W, H, prm, sample_no, 0)
+        fwd = [_f32(v) for v in cam["forward"][0]]
+        up = [_f32(v) for v in cam["up"][0]]
+        dx, dy = _f32(cam["dims"][0][0]), _f32(cam["dims"][0][1])
+        focal = _f32(cam["focal_length"][0])
+        right = _cross3(fwd, up)
+        top_left = [(fwd[k] * focal + up[k] * dy) - right[k] * dx for k in range(3)]
+        for i in range(0, len(src), 97):
+            vals, _ = po.rng_sequence(po.rng_init(prm.seed, i, sample_no), 2)
+            jx, jy = _f32(vals[0]) / _f32(W), _f32(vals[1]) / _f32(H)  # x takes the first draw
+            sx, sy = _f32(src["screen_pos"][i][0]) + jx, _f32(src["screen_pos"][i][1]) + jy
+            d = [top_left[k] + ((((up[k] * _f32(-2.0)) * dy) * sy) + (((right[k] * _f32(2.0)) * dx) * sx)) for k in range(3)]
+            inv_len = _f32(1.0) / np.sqrt(_dot3(d, d))
+            want = np.array([d[k] * inv_len for k in range(3)], "<f4")
+            assert np.array_equal(rays["dir"][i].view("<u4"), want.view("<u4")), (sample_no, i)
+            assert np.array_equal(rays["pos"][i], cam["position"][0])
+            assert rays["last_inst"][i] == rays["last_prim"][i] == 0x7FFFFFFF  # int.maxValue
+
+
+def test_tone_map_and_pixel_packing_against_a_numpy_restatement_of_the_shader_text():
+    # acesToneMap + packRgb (shaders/sample.slang:18-33,52-56; shaders/common.slang:177-183) in numpy
+    # float32, on the mean over the FINAL count (the documented difference from the reference)
+    rng = np.random.default_rng(4)
+    W, H = 16, 8
+    src = host.make_sample_sources(W, H, 3)
+    n = W * H
+    cnt = rng.integers(0, 9, n).astype("<u4")
+    s4 = np.zeros((n, 4), "<u4")
+    s4[:, :3] = (rng.random((n, 3)) ** 3 * 40000.0 * np.maximum(cnt, 1)[:, None]).astype("<u4")
+    prm = po.default_params()
+    got = po.resolve(s4.reshape(-1).copy(), cnt, src, W, H, prm)
+    m1 = np.array([[0.59719, 0.35458, 0.04823], [0.07600, 0.90834, 0.01566], [0.02840, 0.13383, 0.83770]], "<f4")
+    m2 = np.array([[1.60475, -0.53108, -0.07367], [-0.10208, 1.10813, -0.00605], [-0.00327, -0.07276, 1.07602]], "<f4")
+    sat = lambda x: _f32(0.0) if x < 0 else (_f32(1.0) if x > 1 else x)
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            ox, oy = int(src["out_pos"][i][0]), int(src["out_pos"][i][1])
+            if cnt[i] == 0:
+                assert got[ox + oy * W] == 0
+                continue
+            denom = _f32(1000.0) * _f32(cnt[i])
+            rad = [(_f32(s4[i][k]) / denom) * _f32(prm.exposure) for k in range(3)]
+            v = [m1[k][0] * rad[0] + m1[k][1] * rad[1] + m1[k][2] * rad[2] for k in range(3)]
+            c = [(v[k] * (v[k] + _f32(0.0245786)) - _f32(0.000090537)) /
+                 (v[k] * (_f32(0.983729) * v[k] + _f32(0.4329510)) + _f32(0.238081)) for k in range(3)]
+            o = [sat(m2[k][0] * c[0] + m2[k][1] * c[1] + m2[k][2] * c[2]) for k in range(3)]
+            r, g, b = (int(np.uint32(o[k] * _f32(255.0))) for k in range(3))
+            assert got[ox + oy * W] == (b << 16) | (g << 8) | r, i  # .bgr swizzle: red in the low byte
+
+
+def test_triangle_test_against_a_numpy_restatement_of_the_shader_text():
+    # rayTriIntersect (shaders/ray_extend.slang:53-92) a second time in numpy float32, on the rect
+    # mesh under an identity transform (object space = world space): hit triangle, t bits and
+    # front_face of the C oracle's traversal for rays that clearly hit or clearly miss
+    s = host.Scene()
+    rect = s.load_rect()
+    mat = s.add_material(host.default_material())
+    s.spawn(host.make_transform(), mat, rect)
+    arrays = s.bind()
+    pos4, _, faces, _ = s.mesh(rect)
+    s.close()
+    sc = po.Scene(arrays)
+    rng = np.random.default_rng(21)
+    n = 400
+    rays = np.zeros(n, ffi.Ray)
+    target = rng.uniform(-0.75, 0.75, (n, 2))
+    target = target[(np.abs(np.abs(target) - 0.5) > 0.05).all(axis=1)]  # stay off the rect's edges
+    n = len(target)
+    rays = rays[:n]
+    origin = np.c_[rng.uniform(-1.0, 1.0, (n, 2)), rng.choice([-2.0, 1.5], n)]
+    d = np.c_[target, np.zeros(n)] - origin
+    rays["pos"] = origin.astype("<f4")
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype("<f4")
+    rays["last_inst"] = rays["last_prim"] = ffi.NO_PRIM
+    got = sc.trace_closest(rays)
+    hits = 0
+    for i in range(n):
+        pos = [_f32(v) for v in rays["pos"][i]]
+        dr = [_f32(v) for v in rays["dir"][i]]
+        t, prim = np.float32(3.4028234663852886e38), None
+        for p, face in enumerate(faces):
+            p0, p1, p2 = ([_f32(v) for v in pos4[face[k]][:3]] for k in range(3))
+            e1 = [p1[k] - p0[k] for k in range(3)]
+            e2 = [p2[k] - p0[k] for k in range(3)]
+            q = _cross3(dr, e2)
+            alpha = _dot3(e1, q)
+            if -_f32(10e-8) < alpha < _f32(10e-8):
+                continue
+            f = _f32(1.0) / alpha
+            sv = [pos[k] - p0[k] for k in range(3)]
+            u = f * _dot3(sv, q)
+            if u < 0:
+                continue
+            r = _cross3(sv, e1)
+            v = f * _dot3(dr, r)
+            if v < 0 or u + v > 1:
+                continue
+            t2 = f * _dot3(e2, r)
+            if t2 > t or t2 < 0:
+                continue
+            t, prim = t2, p  # an equal t replaces the earlier hit
+        inside = bool((np.abs(target[i]) < 0.5).all())
+        assert (prim is not None) == inside, i
+        if prim is None:
+            assert got["instance_id"][i] == 0xFFFFFFFF
+        else:
+            hits += 1
+            assert got["instance_id"][i] == 0 and got["triangle_id"][i] == prim, i
+            assert got["t"][i].view("<u4") == np.float32(t).view("<u4"), i
+            # the rect's normal is +z; front_face = dot(normal, dir) < 0
+            assert got["front_face"][i] == (1 if dr[2] < 0 else 0), i
+    assert 50 < hits < n - 50
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
