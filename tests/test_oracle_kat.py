@@ -296,6 +296,165 @@ def test_triangle_test_against_a_numpy_restatement_of_the_shader_text():
     assert 50 < hits < n - 50
 
 
+def _normalize3(a):
+    inv = _f32(1.0) / np.sqrt(_dot3(a, a))
+    return [a[k] * inv for k in range(3)]
+
+
+def _camera_dir(cam, src_row, W, H, r1, r2):
+    fwd = [_f32(v) for v in cam["forward"][0]]
+    up = [_f32(v) for v in cam["up"][0]]
+    dx, dy = _f32(cam["dims"][0][0]), _f32(cam["dims"][0][1])
+    right = _cross3(fwd, up)
+    top_left = [(fwd[k] * _f32(cam["focal_length"][0]) + up[k] * dy) - right[k] * dx for k in range(3)]
+    sx = _f32(src_row["screen_pos"][0]) + _f32(r1) / _f32(W)
+    sy = _f32(src_row["screen_pos"][1]) + _f32(r2) / _f32(H)
+    d = [top_left[k] + ((((up[k] * _f32(-2.0)) * dy) * sy) + (((right[k] * _f32(2.0)) * dx) * sx)) for k in range(3)]
+    return _normalize3(d)
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_uber_shading_against_a_numpy_restatement_of_the_shader_text(flip):
+    # One bounce of shadeMain (shaders/shade.slang:19-224) — emission, the dead draws, the cosine
+    # sample, the glTF metal-rough BRDF, the throughput update — a second time in numpy float32:
+    # a camera ray hits a big rect (seen from its back or, flipped in z, from its front), is shaded once
+    # and leaves for the sky, so the sample's radiance is throughput x sky and its fixed-point sum
+    # must equal the C oracle's.
+    PI = _f32(3.14159265)
+    W, H = 12, 8
+    rng = np.random.default_rng(8 + flip)
+    mats = []
+    for _ in range(5):
+        mats.append(dict(colour=tuple(rng.uniform(0.1, 1.0, 3)) + (1.0,), metallic=float(rng.choice([0.0, 1.0, rng.random()])),
+                         roughness=float(rng.uniform(0.05, 1.0)), ior=float(rng.uniform(1.1, 2.0)),
+                         transmission=float(rng.choice([0.0, 1.0, rng.random()]))))
+    src = host.make_sample_sources(W, H, 5)
+    cam = host.default_camera(W, H)
+    sz = -1.0 if flip else 1.0
+    for mi, mk in enumerate(mats):
+        s = host.Scene()
+        rect = s.load_rect()
+        m = host.make_material(**mk)
+        mid = s.add_material(m)
+        s.spawn(host.make_transform(scale=(16.0, 16.0, sz), translation=(0.0, 0.0, 3.0)), mid, rect)
+        arrays = s.bind()
+        pos4, nrm4, faces, _ = s.mesh(rect)
+        s.close()
+        prm = po.default_params(max_bounces=2, seed=100 + mi)
+        got4, gotc, _ = po.Scene(arrays).render(cam, src, W, H, prm, 0, 1)
+        colour = [_f32(v) for v in mk["colour"][:3]]
+        metallic, rough, ior, trans = (_f32(mk[k]) for k in ("metallic", "roughness", "ior", "transmission"))
+        with np.errstate(all="ignore"):
+            for i in range(0, len(src), 7):
+                draws, _ = po.rng_sequence(po.rng_init(prm.seed, i, 0), 200)
+                draws = [_f32(v) for v in draws]
+                wdir = _camera_dir(cam, src[i], W, H, draws[0], draws[1])
+                at = [2]
+
+                def nxt():
+                    at[0] += 1
+                    return draws[at[0] - 1]
+                # object space: M^-1 = S^-1 T^-1 with scale (16, 16, sz), translation (0, 0, 3): exact in f32
+                opos = [_f32(0.0), _f32(0.0), _f32(-3.0) * _f32(1.0 / sz)]
+                odir = [wdir[0] * _f32(0.0625), wdir[1] * _f32(0.0625), wdir[2] * _f32(1.0 / sz)]
+                hit = None
+                t = np.float32(3.4028234663852886e38)
+                for p, face in enumerate(faces):
+                    p0, p1, p2 = ([_f32(v) for v in pos4[face[k]][:3]] for k in range(3))
+                    e1 = [p1[k] - p0[k] for k in range(3)]
+                    e2 = [p2[k] - p0[k] for k in range(3)]
+                    q = _cross3(odir, e2)
+                    alpha = _dot3(e1, q)
+                    if -_f32(10e-8) < alpha < _f32(10e-8):
+                        continue
+                    f = _f32(1.0) / alpha
+                    sv = [opos[k] - p0[k] for k in range(3)]
+                    u = f * _dot3(sv, q)
+                    if u < 0:
+                        continue
+                    r = _cross3(sv, e1)
+                    v = f * _dot3(odir, r)
+                    if v < 0 or u + v > 1:
+                        continue
+                    t2 = f * _dot3(e2, r)
+                    if t2 > t or t2 < 0:
+                        continue
+                    t, hit = t2, (p, u, v)
+                assert hit is not None  # the rect fills the view
+                p, u, v = hit
+                w = _f32(1.0) - u - v
+                n0, n1, n2 = ([_f32(x) for x in nrm4[faces[p][k]][:3]] for k in range(3))
+                nobj = [_fma(n2[k], v, _fma(n1[k], u, n0[k] * w)) for k in range(3)]
+                normal = _normalize3([nobj[0] * _f32(16.0), nobj[1] * _f32(16.0), nobj[2] * _f32(sz)])  # M, not M^-T
+                ff = _dot3(normal, wdir) < 0
+                assert ff == flip  # unflipped, the rect's +z normal points away from the camera
+                n = [x * (_f32(1.0) if ff else _f32(-1.0)) for x in normal]
+                wo = wdir  # the incoming direction, not negated
+
+                def disk():
+                    while True:
+                        px = _f32(2.0) * nxt() - _f32(1.0)
+                        py = _f32(2.0) * nxt() - _f32(1.0)
+                        if not np.sqrt(_fma(py, py, px * px)) > 1:
+                            return px, py
+
+                def cosine_sample():
+                    dx, dy = disk()
+                    z = np.sqrt(max(_f32(0.0), _f32(1.0) - dx * dx - dy * dy))
+                    temp = [_f32(0), _f32(1), _f32(0)] if abs(n[0]) > _f32(0.9) else [_f32(1), _f32(0), _f32(0)]
+                    t1 = _normalize3(_cross3(n, temp))
+                    t2_ = _cross3(n, t1)
+                    nn = _normalize3(n)
+                    return [_fma(nn[k], z, _fma(t2_[k], dy, t1[k] * dx)) for k in range(3)]
+                cosine_sample()  # diffuse_sample: unused, its draws are not
+                while True:      # metallicSample -> unitSphereSample: three draws per try
+                    r3 = [nxt(), nxt(), nxt()]
+                    if not np.sqrt(_dot3(r3, r3)) > 1:
+                        break
+                wi = cosine_sample()
+                pdf = abs(_dot3(wi, n)) / PI
+                heav = lambda x: _f32(1.0) if x > 0 else _f32(0.0)
+                pow5 = lambda x: np.float32(np.nan) if x < 0 else ((x * x) * (x * x)) * x
+                alpha_r = rough * rough
+                a2 = alpha_r * alpha_r
+                h = _normalize3([wo[k] + wi[k] for k in range(3)])
+                fres = pow5(_f32(1.0) - abs(_dot3(wo, h)))
+                nh = _dot3(n, h)
+                d = a2 * heav(nh)
+                d = d / (PI * ((nh * nh) * (a2 - _f32(1.0)) + _f32(1.0)) ** 2)
+                nwi, nwo = _dot3(n, wi), _dot3(n, wo)
+                vis = heav(_dot3(h, wi)) / (abs(nwi) + np.sqrt(a2 + (_f32(1.0) - a2) * (nwi * nwi)))
+                vis = vis * (heav(_dot3(h, wo)) / (abs(nwo) + np.sqrt(a2 + (_f32(1.0) - a2) * (nwo * nwo))))
+                spec = vis * d
+                k2 = _f32(2.0) * nwi
+                ht = _normalize3([(wo[k] - n[k] * k2) + wi[k] for k in range(3)])
+                nht = _dot3(n, ht)
+                dt = a2 * heav(nht)
+                dt = dt / (PI * ((nht * nht) * (a2 - _f32(1.0)) + _f32(1.0)) ** 2)
+                vt = heav(_dot3(ht, wi) / nwi)
+                vt = vt * heav(_dot3(ht, wo) / nwo)
+                vt = vt / (abs(nwi) + np.sqrt(a2 + (_f32(1.0) - a2)) * (nwi * nwi))
+                vt = vt / (abs(nwo) + np.sqrt(a2 + (_f32(1.0) - a2)) * (nwo * nwo))
+                btdf = vt * dt
+                mix = lambda a, b, mm: (_f32(1.0) - mm) * a + mm * b
+                f0 = ((_f32(1.0) - ior) / (_f32(1.0) + ior)) ** 2
+                fr = f0 + (_f32(1.0) - f0) * fres
+                ndotwi = abs(_dot3(n, wi))
+                for c in range(3):
+                    base = mix(colour[c] * (_f32(1.0) / PI), colour[c] * btdf, trans)
+                    dielectric = mix(base, spec, fr)
+                    metal = spec * (colour[c] + (_f32(1.0) - colour[c]) * fres)
+                    brdf = mix(dielectric, metal, metallic)
+                    thr = _f32(1.0) * (brdf * ndotwi * _f32(1.0) / pdf)
+                    rad = _f32(0.0) + thr * _f32(10.0)  # the sky ends the path
+                    if np.isnan(rad) or np.isinf(rad):
+                        rad = _f32(0.0)
+                    x = rad * _f32(1000.0)
+                    want = 0 if not x >= 0 else (4294967040 if x >= 4294967040.0 else int(np.uint32(x)))
+                    assert int(got4[4 * i + c]) == want, (mi, i, c)
+                assert gotc[i] == 1
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
