@@ -455,6 +455,120 @@ def test_uber_shading_against_a_numpy_restatement_of_the_shader_text(flip):
                 assert gotc[i] == 1
 
 
+def test_traversal_and_visit_counts_against_a_python_restatement_of_the_shader_text():
+    # rayBoxIntersect, blasFirstHit and tlasFirstHit (shaders/ray_extend.slang:94-215) a second time,
+    # as Python loops over the flat scene buffers with numpy float32 scalars: hit ids, t bits and the
+    # node / instance / triangle visit counts the bandwidth model is built on.  Translation-only
+    # instances keep the instance matrices exact without trigonometry.
+    s = host.Scene()
+    suz = s.load_model_file(os.path.join(GOLDEN, "suzanne.mirtmesh"))
+    cube, rect = s.load_cube(), s.load_rect()
+    mat = s.add_material(host.default_material())
+    places = [(suz, (0.0, 0.0, 3.0)), (cube, (1.25, 0.5, 4.0)), (rect, (-1.0, 0.25, 3.5)), (cube, (-0.5, -1.0, 2.5))]
+    for mesh, tr in places:
+        s.spawn(host.make_transform(translation=tr), mat, mesh)
+    arrays = s.bind()
+    s.close()
+    sc = po.Scene(arrays)
+    rays = random_rays(60, 12, centre=(0.0, 0.0, 3.0), spread=1.5)
+    rays["last_inst"][:10] = 0  # some rays carry an excluded triangle of instance 0
+    rays["last_prim"][:10] = np.arange(10) * 7
+    got, gc = sc.trace_closest(rays, want_counts=True)
+
+    inst, offs = arrays["instances"], arrays["geometry_offsets"]
+    verts, idx = arrays["vertices"], arrays["indices"]
+    bn, tn, t2i, xf = arrays["blas_nodes"], arrays["tlas_nodes"], arrays["tlas_to_instances"], arrays["transforms"]
+    FMAX = np.float32(3.4028234663852886e38)
+    counts = dict(tlas=0, inst=0, blas=0, tri=0)
+    fmax = lambda a, b: b if np.isnan(a) else (a if np.isnan(b) else (a if a > b else b))
+    fmin = lambda a, b: b if np.isnan(a) else (a if np.isnan(b) else (a if a < b else b))
+
+    def box(pos, dinv, node, t):
+        tmin, tmax = -FMAX, t
+        for d in range(3):
+            sign = dinv[d] >= 0
+            lo, hi = _f32(node["lb"][d]), _f32(node["ub"][d])
+            bmin, bmax = (lo, hi) if sign else (hi, lo)
+            tmin = fmax((bmin - pos[d]) * dinv[d], tmin)
+            tmax = fmin((bmax - pos[d]) * dinv[d], tmax)
+        return tmin <= tmax, tmin, tmax
+
+    def tri(pos, dr, face, voff, t):
+        p0, p1, p2 = ([_f32(x) for x in verts[voff + int(face["v"][k])]["position"][:3]] for k in range(3))
+        e1 = [p1[k] - p0[k] for k in range(3)]
+        e2 = [p2[k] - p0[k] for k in range(3)]
+        q = _cross3(dr, e2)
+        alpha = _dot3(e1, q)
+        if -_f32(10e-8) < alpha < _f32(10e-8):
+            return None
+        f = _f32(1.0) / alpha
+        sv = [pos[k] - p0[k] for k in range(3)]
+        u = f * _dot3(sv, q)
+        if u < 0:
+            return None
+        r = _cross3(sv, e1)
+        v = f * _dot3(dr, r)
+        if v < 0 or u + v > 1:
+            return None
+        t2 = f * _dot3(e2, r)
+        if t2 > t or t2 < 0:
+            return None
+        return t2
+
+    def blas(pos, dr, iid, last_inst, last_prim, t):
+        off = offs[int(inst[iid]["geometry"])]
+        dinv = [_f32(1.0) / dr[k] for k in range(3)]
+        cur, best = 0, None
+        while True:
+            node = bn[cur + int(off["blas_node"])]
+            counts["blas"] += 1
+            hit, _, _ = box(pos, dinv, node, t)
+            cur = int(node["right"]) if (node["is_leaf"] == 1 or not hit) else int(node["left"])
+            if hit and node["is_leaf"] == 1:
+                for p in range(int(node["start"]), int(node["end"])):
+                    if p == last_prim and iid == last_inst:
+                        continue
+                    counts["tri"] += 1
+                    t2 = tri(pos, dr, idx[p + int(off["index"])], int(off["vertex"]), t)
+                    if t2 is not None:
+                        t, best = t2, p
+            if cur == 0:
+                return best, t
+
+    with np.errstate(all="ignore"):
+        for i in range(len(rays)):
+            pos = [_f32(x) for x in rays["pos"][i]]
+            dr = [_f32(x) for x in rays["dir"][i]]
+            li, lp = int(rays["last_inst"][i]), int(rays["last_prim"][i])
+            dinv = [_f32(1.0) / dr[k] for k in range(3)]
+            t, cur, best = FMAX, 0, None
+            while True:
+                node = tn[cur]
+                counts["tlas"] += 1
+                hit, tmin, tmax = box(pos, dinv, node, t)
+                hit = hit and (tmax >= 0 or tmin >= 0)
+                cur = int(node["right"]) if (node["is_leaf"] == 1 or not hit) else int(node["left"])
+                if hit and node["is_leaf"] == 1:
+                    for slot in range(int(node["start"]), int(node["end"])):
+                        iid = int(t2i[slot])
+                        counts["inst"] += 1
+                        tr = [_f32(x) for x in xf[int(inst[iid]["transform"])]["translation"][:3]]
+                        opos = [pos[k] + (-tr[k]) for k in range(3)]  # M^-1 of a pure translation
+                        p, t2 = blas(opos, dr, iid, li, lp, t)
+                        if p is not None:
+                            t, best = t2, (iid, p)
+                if cur == 0:
+                    break
+            if best is None:
+                assert got["instance_id"][i] == 0xFFFFFFFF, i
+            else:
+                assert (int(got["instance_id"][i]), int(got["triangle_id"][i])) == best, i
+                assert got["t"][i].view("<u4") == np.float32(t).view("<u4"), i
+    assert (gc.tlas_nodes, gc.instance_visits, gc.blas_nodes, gc.triangles) == \
+           (counts["tlas"], counts["inst"], counts["blas"], counts["tri"])
+    assert (got["instance_id"] != 0xFFFFFFFF).sum() > 10
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
