@@ -569,6 +569,139 @@ def test_traversal_and_visit_counts_against_a_python_restatement_of_the_shader_t
     assert (got["instance_id"] != 0xFFFFFFFF).sum() > 10
 
 
+def _rect_hit(wdir, sz, pos4, nrm4, faces):
+    """Camera ray from the origin against the rect scaled (16, 16, sz) at (0, 0, 3): rayTriIntersect in
+    object space and the hit record of extensionMain (position, normal, front_face), in numpy float32."""
+    opos = [_f32(0.0), _f32(0.0), _f32(-3.0) * _f32(1.0 / sz)]
+    odir = [wdir[0] * _f32(0.0625), wdir[1] * _f32(0.0625), wdir[2] * _f32(1.0 / sz)]
+    hit, t = None, np.float32(3.4028234663852886e38)
+    for p, face in enumerate(faces):
+        p0, p1, p2 = ([_f32(v) for v in pos4[face[k]][:3]] for k in range(3))
+        e1 = [p1[k] - p0[k] for k in range(3)]
+        e2 = [p2[k] - p0[k] for k in range(3)]
+        q = _cross3(odir, e2)
+        alpha = _dot3(e1, q)
+        if -_f32(10e-8) < alpha < _f32(10e-8):
+            continue
+        f = _f32(1.0) / alpha
+        sv = [opos[k] - p0[k] for k in range(3)]
+        u = f * _dot3(sv, q)
+        if u < 0:
+            continue
+        r = _cross3(sv, e1)
+        v = f * _dot3(odir, r)
+        if v < 0 or u + v > 1:
+            continue
+        t2 = f * _dot3(e2, r)
+        if t2 > t or t2 < 0:
+            continue
+        t, hit = t2, (p, u, v, p0, e1, e2)
+    assert hit is not None
+    p, u, v, p0, e1, e2 = hit
+    w = _f32(1.0) - u - v
+    n0, n1, n2 = ([_f32(x) for x in nrm4[faces[p][k]][:3]] for k in range(3))
+    nobj = [_fma(n2[k], v, _fma(n1[k], u, n0[k] * w)) for k in range(3)]
+    pobj = [_fma(e2[k], v, _fma(e1[k], u, p0[k])) for k in range(3)]
+    # M = T S: rows (16, 0, 0 | 0), (0, 16, 0 | 0), (0, 0, sz | 3), as fma(m2, z, fma(m1, y, m0 * x)) + m3
+    hpos = [_fma(_f32(0), pobj[2], _fma(_f32(0), pobj[1], _f32(16.0) * pobj[0])) + _f32(0.0),
+            _fma(_f32(0), pobj[2], _fma(_f32(16.0), pobj[1], _f32(0) * pobj[0])) + _f32(0.0),
+            _fma(_f32(sz), pobj[2], _fma(_f32(0), pobj[1], _f32(0) * pobj[0])) + _f32(3.0)]
+    normal = _normalize3([nobj[0] * _f32(16.0), nobj[1] * _f32(16.0), nobj[2] * _f32(sz)])
+    ff = bool(_dot3(normal, wdir) < 0)
+    return hpos, normal, ff
+
+
+@pytest.mark.parametrize("kind", ["lambertian", "metallic", "dielectric"])
+def test_per_material_kernels_against_a_numpy_restatement(kind):
+    # One bounce of the per-material path without light sampling — the scatter of
+    # archive/lambertian.slang:26-35 inside process_material (archive/material.slang:17-139),
+    # archive/metallic.slang:65-96, archive/dielectric.slang:34-95 with the documented repairs — a
+    # second time in numpy float32: the bounce ray (origin and direction bits) and, the ray then
+    # leaving for the sky, the sample's fixed-point sums.
+    W, H = 12, 8
+    src = host.make_sample_sources(W, H, 6)
+    cam = host.default_camera(W, H)
+    rng = np.random.default_rng({"lambertian": 1, "metallic": 2, "dielectric": 3}[kind])
+    for flip in (False, True):
+        sz = -1.0 if flip else 1.0
+        colour = tuple(float(x) for x in rng.uniform(0.2, 0.9, 3)) + (1.0,)
+        mk = dict(colour=colour, metallic=1.0 if kind == "metallic" else 0.0, roughness=0.125,
+                  ior=float(rng.uniform(1.2, 1.8)), transmission=1.0 if kind == "dielectric" else 0.0)
+        s = host.Scene()
+        rect = s.load_rect()
+        mid = s.add_material(host.make_material(**mk))
+        s.spawn(host.make_transform(scale=(16.0, 16.0, sz), translation=(0.0, 0.0, 3.0)), mid, rect)
+        arrays = s.bind()
+        pos4, nrm4, faces, _ = s.mesh(rect)
+        s.close()
+        prm = po.default_params(max_bounces=3, seed=300 + flip, shade_mode=1)
+        sc = po.Scene(arrays)
+        got4, gotc, _ = sc.render(cam, src, W, H, prm, 0, 1)
+        rays = sc.bounce_rays(cam, src, W, H, prm, 0, 1)
+        albedo = [_f32(v) for v in colour[:3]]
+        with np.errstate(all="ignore"):
+            for i in range(0, len(src), 5):
+                draws, _ = po.rng_sequence(po.rng_init(prm.seed, i, 0), 8)
+                draws = [_f32(v) for v in draws]
+                wdir = _camera_dir(cam, src[i], W, H, draws[0], draws[1])
+                hpos, normal, ff = _rect_hit(wdir, sz, pos4, nrm4, faces)
+                nf = [x * (_f32(1.0) if ff else _f32(-1.0)) for x in normal]
+                a, b, c = draws[2], draws[3], draws[4]
+                unit = lambda: _normalize3([_f32(1.0) - _f32(2.0) * a, _f32(1.0) - _f32(2.0) * b, _f32(1.0) - _f32(2.0) * c])
+                thr = [_f32(1.0)] * 3
+                if kind == "lambertian":
+                    wo = [-x for x in wdir]
+                    scv = [nf[k] + unit()[k] for k in range(3)]
+                    wi = _normalize3(nf if np.sqrt(_dot3(scv, scv)) < _f32(1e-6) else scv)
+                    pdf = max(_f32(0.0), _dot3(wi, nf)) / _f32(3.1415)
+                    assert pdf > 0
+                    lit = not (_dot3(nf, wi) <= 0 or _dot3(nf, wo) <= 0)
+                    for k in range(3):
+                        x = thr[k] * (albedo[k] / _f32(3.1415) if lit else _f32(0.0))
+                        x = x * _dot3(wi, nf)
+                        x = x * ((_f32(1.0) * pdf) / (_f32(1.0) * pdf + _f32(1.0) * _f32(0.0)))
+                        thr[k] = x / (_f32(1.0) * pdf)
+                    new_pos = [hpos[k] + nf[k] * _f32(1e-3) for k in range(3)]
+                    new_dir = wi
+                elif kind == "metallic":
+                    thr = [thr[k] * albedo[k] for k in range(3)]
+                    k2 = _f32(2.0) * _dot3(wdir, nf)
+                    refl = [wdir[k] - nf[k] * k2 for k in range(3)]
+                    fz = unit()
+                    scv = [refl[k] + fz[k] * _f32(0.125) for k in range(3)]
+                    new_dir = _normalize3(refl if np.sqrt(_dot3(scv, scv)) < _f32(1e-2) else scv)
+                    new_pos = [hpos[k] + nf[k] * _f32(0.005) for k in range(3)]
+                else:
+                    ir = _f32(mk["ior"])
+                    ratio = _f32(1.0) / ir if ff else ir
+                    ud = _normalize3(wdir)
+                    cos_t = min(-_dot3(ud, nf), _f32(1.0))
+                    sin_t = np.sqrt(max(_f32(0.0), _f32(1.0) - cos_t * cos_t))
+                    r0 = (_f32(1.0) - ratio) / (_f32(1.0) + ratio)
+                    r0 = r0 * r0
+                    om = _f32(1.0) - cos_t
+                    refl_p = r0 + (_f32(1.0) - r0) * (np.float32(np.nan) if om < 0 else ((om * om) * (om * om)) * om)
+                    if ratio * sin_t > 1 or refl_p > draws[2]:
+                        k2 = _f32(2.0) * _dot3(ud, nf)
+                        scv = [ud[k] - nf[k] * k2 for k in range(3)]
+                        new_pos = [hpos[k] + nf[k] * _f32(1e-4) for k in range(3)]
+                    else:
+                        perp = [(ud[k] + nf[k] * cos_t) * ratio for k in range(3)]
+                        kk = _f32(1.0) - _dot3(perp, perp)
+                        par = -np.sqrt(max(kk, _f32(0.0)))
+                        scv = [perp[k] + nf[k] * par for k in range(3)]
+                        new_pos = [hpos[k] - nf[k] * _f32(1e-4) for k in range(3)]
+                    thr = [thr[k] * albedo[k] for k in range(3)]
+                    new_dir = _normalize3(scv)
+                assert np.array_equal(rays["pos"][i].view("<u4"), np.array(new_pos, "<f4").view("<u4")), (flip, i)
+                assert np.array_equal(rays["dir"][i].view("<u4"), np.array(new_dir, "<f4").view("<u4")), (flip, i)
+                assert rays["last_inst"][i] == rays["last_prim"][i] == 0x7FFFFFFF  # origins are offset instead
+                for k in range(3):
+                    x = (_f32(0.0) + thr[k] * _f32(10.0)) * _f32(1000.0)
+                    assert int(got4[4 * i + k]) == int(np.uint32(x)), (flip, i, k)
+                assert gotc[i] == 1
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
