@@ -702,6 +702,115 @@ def test_per_material_kernels_against_a_numpy_restatement(kind):
                 assert gotc[i] == 1
 
 
+def test_instance_matrices_against_a_numpy_restatement_of_the_shader_text():
+    # Transform.matrix() / matrix_inverse() (shaders/common.slang:41-111) a second time: 4x4
+    # products summed left to right in numpy float32 with the C library's sinf / cosf, observed
+    # through a rotated, scaled, translated rect — rays moved to object space with M^-1, the
+    # triangle test there, front_face from normalize(M n) — against the C oracle's hits
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    sin = lambda x: _f32(libm.sinf(float(x)))
+    cos = lambda x: _f32(libm.cosf(float(x)))
+
+    def mul(a, b):
+        o = [[None] * 4 for _ in range(4)]
+        for i in range(4):
+            for j in range(4):
+                acc = a[i][0] * b[0][j]
+                for k in (1, 2, 3):
+                    acc = acc + a[i][k] * b[k][j]
+                o[i][j] = acc
+        return o
+
+    def ident():
+        return [[_f32(1.0 if i == j else 0.0) for j in range(4)] for i in range(4)]
+
+    scale, rot, tr = (2.0, 0.75, 1.5), (0.4, -1.1, 2.3), (0.3, -0.2, 3.0)
+    sc_, ro, tl = ([_f32(v) for v in x] for x in (scale, rot, tr))
+    rx, ry, rz = ident(), ident(), ident()
+    rx[1][1], rx[1][2], rx[2][1], rx[2][2] = cos(ro[0]), -sin(ro[0]), sin(ro[0]), cos(ro[0])
+    ry[0][0], ry[0][2], ry[2][0], ry[2][2] = cos(ro[1]), sin(ro[1]), -sin(ro[1]), cos(ro[1])
+    rz[0][0], rz[0][1], rz[1][0], rz[1][1] = cos(ro[2]), -sin(ro[2]), sin(ro[2]), cos(ro[2])
+    R = mul(rx, mul(ry, rz))
+    S, T, Si, Ti = ident(), ident(), ident(), ident()
+    for k in range(3):
+        S[k][k] = sc_[k]
+        Si[k][k] = _f32(1.0) / sc_[k]
+        T[k][3] = tl[k]
+        Ti[k][3] = -tl[k]
+    M = mul(T, mul(R, S))
+    Rt = [[R[j][i] for j in range(4)] for i in range(4)]
+    Mi = mul(Si, mul(Rt, Ti))
+    xv = lambda m, p: [_fma(m[r][2], p[2], _fma(m[r][1], p[1], m[r][0] * p[0])) for r in range(3)]
+    xp = lambda m, p: [xv(m, p)[r] + m[r][3] for r in range(3)]
+
+    s = host.Scene()
+    rect = s.load_rect()
+    mat = s.add_material(host.default_material())
+    s.spawn(host.make_transform(scale=scale, rotation=rot, translation=tr), mat, rect)
+    arrays = s.bind()
+    pos4, nrm4, faces, _ = s.mesh(rect)
+    s.close()
+    rng = np.random.default_rng(31)
+    n = 300
+    uv = rng.uniform(-0.8, 0.8, (n, 2))
+    uv = uv[(np.abs(np.abs(uv) - 0.5) > 0.04).all(axis=1)]  # clearly inside or clearly outside the rect
+    n = len(uv)
+    target = np.array([[float(x) for x in xp(M, [_f32(a), _f32(b), _f32(0.0)])] for a, b in uv])
+    origin = rng.uniform(-2.0, 2.0, (n, 3)) + np.array([0.0, 0.0, 0.5])
+    d = target - origin
+    rays = np.zeros(n, ffi.Ray)
+    rays["pos"] = origin.astype("<f4")
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype("<f4")
+    rays["last_inst"] = rays["last_prim"] = ffi.NO_PRIM
+    got = po.Scene(arrays).trace_closest(rays)
+    hits = 0
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            wpos = [_f32(v) for v in rays["pos"][i]]
+            wdir = [_f32(v) for v in rays["dir"][i]]
+            opos, odir = xp(Mi, wpos), xv(Mi, wdir)  # the direction is not renormalised: t stays in world units
+            best, t = None, np.float32(3.4028234663852886e38)
+            for p, face in enumerate(faces):
+                p0, p1, p2 = ([_f32(v) for v in pos4[face[k]][:3]] for k in range(3))
+                e1 = [p1[k] - p0[k] for k in range(3)]
+                e2 = [p2[k] - p0[k] for k in range(3)]
+                q = _cross3(odir, e2)
+                alpha = _dot3(e1, q)
+                if -_f32(10e-8) < alpha < _f32(10e-8):
+                    continue
+                f = _f32(1.0) / alpha
+                sv = [opos[k] - p0[k] for k in range(3)]
+                u = f * _dot3(sv, q)
+                if u < 0:
+                    continue
+                r = _cross3(sv, e1)
+                v = f * _dot3(odir, r)
+                if v < 0 or u + v > 1:
+                    continue
+                t2 = f * _dot3(e2, r)
+                if t2 > t or t2 < 0:
+                    continue
+                t, best = t2, (p, u, v)
+            inside = bool((np.abs(uv[i]) < 0.5).all())
+            assert (best is not None) == inside, i
+            if best is None:
+                assert got["instance_id"][i] == 0xFFFFFFFF, i
+                continue
+            hits += 1
+            p, u, v = best
+            w = _f32(1.0) - u - v
+            n0, n1, n2 = ([_f32(x) for x in nrm4[faces[p][k]][:3]] for k in range(3))
+            nobj = [_fma(n2[k], v, _fma(n1[k], u, n0[k] * w)) for k in range(3)]
+            normal = _normalize3(xv(M, nobj))
+            assert (int(got["instance_id"][i]), int(got["triangle_id"][i])) == (0, p), i
+            assert got["t"][i].view("<u4") == np.float32(t).view("<u4"), i
+            assert got["front_face"][i] == (1 if _dot3(normal, wdir) < 0 else 0), i
+    assert 40 < hits < n - 40
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
