@@ -811,6 +811,111 @@ def test_instance_matrices_against_a_numpy_restatement_of_the_shader_text():
     assert 40 < hits < n - 40
 
 
+def test_light_sampling_and_connect_rays_against_a_numpy_restatement():
+    # The connect stage with its documented repairs (light face drawn uniformly from the light's
+    # BLAS root, point folded into the triangle, any-hit visibility up to the light, pdf from the
+    # transformed edges; archive/light.slang:14-81, archive/shadow.slang:63-139) and the Lambertian
+    # kernel's combination of the light sample with the scatter (archive/material.slang:17-139), a
+    # second time in numpy float32: the shadow ray (origin, direction, tmax, excluded triangle) and
+    # the sample's sums.  A Lambertian floor seen from its front, an emissive rect off-screen above
+    # it, nothing in between; translation and axis scale only, so the matrices are exact.
+    import ctypes as C
+    W, H = 12, 8
+    src = host.make_sample_sources(W, H, 9)
+    cam = host.default_camera(W, H)
+    colour = (0.7, 0.5, 0.3, 1.0)
+    emit = (20.0, 15.0, 10.0, 0.0)
+    light_at = (0.0, 6.0, 1.0)
+    s = host.Scene()
+    rect = s.load_rect()
+    floor_m = s.add_material(host.make_material(colour=colour))
+    light_m = s.add_material(host.make_material(colour=(1.0, 1.0, 1.0, 0.0), emissive=emit))
+    s.spawn(host.make_transform(scale=(16.0, 16.0, -1.0), translation=(0.0, 0.0, 3.0)), floor_m, rect)
+    s.spawn(host.make_transform(translation=light_at), light_m, rect)
+    arrays = s.bind()
+    pos4, nrm4, faces, _ = s.mesh(rect)
+    s.close()
+    assert list(arrays["light_sources"]) == [1]
+    prm = po.default_params(max_bounces=2, seed=77, shade_mode=1, nee=1)
+    sc = po.Scene(arrays)
+    got4, gotc, _ = sc.render(cam, src, W, H, prm, 0, 1)
+    crays = np.zeros(len(src), ffi.Ray)
+    ctmax = np.zeros(len(src), "<f4")
+    po.lib().oracle_connect_rays(sc._h, cam.ctypes.data, src.ctypes.data, len(src), W, H, C.byref(prm), 0, 0,
+                                 crays.ctypes.data, ctmax.ctypes.data)
+    albedo = [_f32(v) for v in colour[:3]]
+    lrad = [_f32(v) for v in emit[:3]]
+    lt = [_f32(v) for v in light_at]
+    checked = 0
+    with np.errstate(all="ignore"):
+        for i in range(0, len(src), 3):
+            draws, _ = po.rng_sequence(po.rng_init(prm.seed, i, 0), 12)
+            draws = [_f32(v) for v in draws]
+            wdir = _camera_dir(cam, src[i], W, H, draws[0], draws[1])
+            hpos, normal, ff = _rect_hit(wdir, -1.0, pos4, nrm4, faces)
+            assert ff
+            nf = normal
+            orig = [hpos[k] + nf[k] * _f32(1e-3) for k in range(3)]
+            r1, r2, a, b = draws[2:6]
+            li = min(int(np.floor(r1 * _f32(1.0))), 0)
+            fi = min(int(np.floor(r2 * _f32(2.0))), 1)
+            face = faces[fi]
+            p0, p1, p2 = ([_f32(v) for v in pos4[face[k]][:3]] for k in range(3))
+            e1 = [p1[k] - p0[k] for k in range(3)]
+            e2 = [p2[k] - p0[k] for k in range(3)]
+            if a + b > 1:
+                a, b = _f32(1.0) - a, _f32(1.0) - b
+            pobj = [(p0[k] + e1[k] * a) + e2[k] * b for k in range(3)]
+            spos = [pobj[k] + lt[k] for k in range(3)]  # M = a pure translation
+            cr = _cross3(e1, e2)
+            area = _f32(0.5) * np.sqrt(_dot3(cr, cr))
+            sprob = (_f32(1.0) / area) * (_f32(1.0) / _f32(2.0))
+            ln = _normalize3(cr)
+            d = [spos[k] - orig[k] for k in range(3)]
+            shadow_t = np.sqrt(_dot3(d, d))
+            scat = _normalize3(d)
+            assert _dot3(scat, nf) > 0  # the light is on the floor's front side
+            assert np.array_equal(crays["pos"][i].view("<u4"), np.array(orig, "<f4").view("<u4")), i
+            assert np.array_equal(crays["dir"][i].view("<u4"), np.array(scat, "<f4").view("<u4")), i
+            assert (int(crays["last_inst"][i]), int(crays["last_prim"][i])) == (1, fi), i
+            assert ctmax[i].view("<u4") == np.float32(shadow_t).view("<u4"), i
+            prob = sprob * _dot3(d, d) / abs(_dot3(ln, [-x for x in scat]))  # nothing occludes
+            # the Lambertian kernel
+            wo = [-x for x in wdir]
+            sa, sb, scc = draws[6], draws[7], draws[8]
+            unit = _normalize3([_f32(1.0) - _f32(2.0) * sa, _f32(1.0) - _f32(2.0) * sb, _f32(1.0) - _f32(2.0) * scc])
+            scv = [nf[k] + unit[k] for k in range(3)]
+            wi = _normalize3(nf if np.sqrt(_dot3(scv, scv)) < _f32(1e-6) else scv)
+            lpdf = lambda w_: max(_f32(0.0), _dot3(w_, nf)) / _f32(3.1415)
+            brdf = lambda w_, k: _f32(0.0) if (_dot3(nf, w_) <= 0 or _dot3(nf, wo) <= 0) else albedo[k] / _f32(3.1415)
+            spdf = lpdf(wi)
+            assert spdf > 0
+            # where the bounce ray goes: leave the rare ones that reach the light's plane near the light alone
+            new_pos = [float(hpos[k] + nf[k] * _f32(1e-3)) for k in range(3)]
+            tt = (1.0 - new_pos[2]) / float(wi[2]) if wi[2] != 0 else -1.0
+            if tt > 0:
+                hx, hy = new_pos[0] + tt * float(wi[0]), new_pos[1] + tt * float(wi[1])
+                if abs(hx) < 0.6 and abs(hy - 6.0) < 0.6:
+                    continue
+            for k in range(3):
+                rad, thr = _f32(0.0), _f32(1.0)
+                if prob > 0:
+                    wgt = (_f32(1.0) * prob) / (_f32(1.0) * prob + _f32(1.0) * lpdf(scat))
+                    c = thr * brdf(scat, k)
+                    c = c * _dot3(scat, nf)
+                    c = c * wgt
+                    c = c / (_f32(1.0) * prob)
+                    rad = rad + lrad[k] * c
+                x = thr * brdf(wi, k)
+                x = x * _dot3(wi, nf)
+                x = x * ((_f32(1.0) * spdf) / (_f32(1.0) * spdf + _f32(1.0) * _f32(0.0)))
+                thr = x / (_f32(1.0) * spdf)
+                rad = rad + thr * _f32(10.0)  # the bounce ray leaves for the sky
+                assert int(got4[4 * i + k]) == int(np.uint32(rad * _f32(1000.0))), (i, k)
+            checked += 1
+    assert checked > 20
+
+
 def test_asset_facts_teapot_takes_the_computed_normal_path():
     s = host.Scene()
     mid = s.load_model_file(os.path.join(GOLDEN, "teapot.mirtmesh"))
