@@ -4,7 +4,9 @@
  * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg as the checker; never part of the product.
  * PARITY UNPINNED by the reference (it has no tests or fixtures); pinned by
- * known-answer values derived from the reference's formulas.
+ * known-answer values derived from the reference's formulas and by a second
+ * restatement of every function of the path, written in numpy float32 from the
+ * shader text (tests/test_oracle_kat.py), that agrees with this one bit for bit.
  *
  * Each function cites the reference lines it restates (paths relative to the
  * reference checkout).  The reference evaluates its arithmetic through

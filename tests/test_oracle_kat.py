@@ -5,7 +5,9 @@ The reference ships no tests, golden vectors or fixtures for this path and
 cannot be built here, so parity with it is UNPINNED; what is pinned is this
 repository's restatement: values derived from the text of the reference's
 formulas (RNG), literal geometry (rect, cube), independent re-implementations
-(pure-Python builder vs C++ builder, brute force vs BVH) and invariants.
+(pure-Python builder vs C++ builder, brute force vs BVH, numpy float32
+restatements of the shader functions written from the shader text vs the C
+oracle) and invariants.
 """
 import json
 import os
