@@ -36,8 +36,7 @@ struct SlotIn {
   uint32_t inst, ff;
 };
 
-// RAW: the hit record still holds what the traversal left (u, v, t, instance;
-// triangle in the last word) and the world-space record of extensionMain
+// RAW: the hit record still holds what the traversal left (u, v, triangle, instance) and the world-space record of extensionMain
 // (shaders/ray_extend.slang:34-50, 204-207) is built here; so is the bounce
 // count of archive/extension.slang:94-101 — a hit costs one bounce, and a path
 // out of bounces ends without being shaded: the function then returns false
@@ -63,9 +62,9 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
     BestHit best;
     best.u = raw.x;
     best.v = raw.y;
-    best.t = raw.z;
+    best.t = 0.0f;
+    best.prim = __float_as_uint(raw.z);
     best.inst = __float_as_uint(raw.w);
-    best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
     finish_hit(sc, s.rdir, best, s.hpos, hn, s.ff);
     s.inst = best.inst;
   } else {

@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp)
 
 // The closest-hit walk of extensionMain (shaders/ray_extend.slang:12-33) for
 // every entry of this frame's extension queue.  It leaves the raw result in the
-// slot's hit record — u, v, t and the instance (kMissInst when nothing was hit)
-// in the first 16 bytes, the triangle id in the last word — for
+// slot's hit record — u, v, the triangle id and the instance (kMissInst when
+// nothing was hit) in its first 16 bytes — for
 // the streaming kernel that follows; keeping the epilogue out of this kernel
 // keeps its registers and instruction footprint small.
 constexpr uint32_t kMissInst = 0xFFFFFFFFu;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, D
   auto finish = [&](bool fin, uint32_t slot, bool found, float t, const BestHit &best) {
     if (fin) {
       float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
-      h4[0] = make_float4(best.u, best.v, t, __uint_as_float(found ? best.inst : kMissInst));
-      reinterpret_cast<uint32_t *>(h4)[7] = best.prim;
+      (void)t;  // nothing downstream reads t: the hit point comes from the barycentrics
+      h4[0] = make_float4(best.u, best.v, __uint_as_float(best.prim), __uint_as_float(found ? best.inst : kMissInst));
     }
   };
   trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
       BestHit best;
       best.u = raw.x;
       best.v = raw.y;
-      best.t = raw.z;
+      best.t = 0.0f;
+      best.prim = __float_as_uint(raw.z);
       best.inst = __float_as_uint(raw.w);
       if (best.inst == kMissInst) {
         // rad += throughput * sky
@@ -299,7 +300,6 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
       } else {
         hit = true;
         if (!RAW) {
-          best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
           const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
           const float4 ra = r4[0], rb = r4[1];
           v3 hp, hn;
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
       BestHit best;
       best.u = raw.x;
       best.v = raw.y;
-      best.t = raw.z;
+      best.t = 0.0f;
+      best.prim = __float_as_uint(raw.z);
       best.inst = __float_as_uint(raw.w);
       if (best.inst == kMissInst) {
         // rad += throughput * sky
@@ -545,7 +546,6 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
           p4[0] = a;
         }
       } else {
-        best.prim = reinterpret_cast<const uint32_t *>(h4)[7];
         v3 rpos, wo, hp, hn;
         uint32_t li, lp, ff;
         load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
