@@ -320,7 +320,10 @@ LaunchCfg launch_cfg(mirt_ctx *c) {
   LaunchCfg cfg;
   cfg.stream = c->stream;
   uint32_t want = c->have_state ? (c->st.slots + kStreamBlock - 1u) / kStreamBlock : 1u;
-  uint32_t cap = (uint32_t)c->num_cus * 2u;  // two 1024-thread blocks fill a CU's 32 wave slots
+#ifndef MIRT_STREAM_BLOCKS_PER_CU
+#define MIRT_STREAM_BLOCKS_PER_CU 2u
+#endif
+  uint32_t cap = (uint32_t)c->num_cus * MIRT_STREAM_BLOCKS_PER_CU;  // two 1024-thread blocks fill a CU's 32 wave slots
   cfg.grid_blocks = (int)(want < cap ? (want ? want : 1u) : cap);
   cfg.num_cus = c->num_cus;
   return cfg;

@@ -368,24 +368,24 @@ void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, co
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
   else hipLaunchKernelGGL((k_connect<false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL(k_connect_finish, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL(k_connect_finish, stream_grid(cfg, k_connect_finish), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   // the four per-material kernels, one queue each (archive frame order:
   // src/app.rs:402-410 dispatches every material phase each frame)
-  const dim3 grid(cfg.grid_blocks), block(kStreamBlock);
+  const dim3 block(kStreamBlock);
   if (fp.p.nee && fp.have_lights) {
-    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, false>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, false>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, false>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, false>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN, false>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, false>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC, false>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, false>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC, false>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, false>), stream_grid(cfg, k_material<MIRT_MAT_EMISSIVE, false>), block, 0, cfg.stream, sc, st, fp);
   } else {
     // no connect kernel: the material kernels build the hit record from the traversal's raw result
-    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, true>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, true>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, true>), grid, block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, true>), grid, block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, true>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN, true>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, true>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC, true>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, true>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC, true>), block, 0, cfg.stream, sc, st, fp);
+    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, true>), stream_grid(cfg, k_material<MIRT_MAT_EMISSIVE, true>), block, 0, cfg.stream, sc, st, fp);
   }
 }
 

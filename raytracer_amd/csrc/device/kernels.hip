@@ -700,7 +700,7 @@ void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFramePara
 }
 
 void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
-  hipLaunchKernelGGL(k_sample, dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+  hipLaunchKernelGGL(k_sample, stream_grid(cfg, k_sample), dim3(kStreamBlock), 0, cfg.stream, st, fp);
 }
 
 // resident waves per SIMD the engine kernels are launched with (blocks per CU x waves per block / 4)
@@ -730,19 +730,19 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const bool raw = !(fp.p.nee && fp.have_lights);  // the connect kernel needs the world-space record
-  const dim3 grid(cfg.grid_blocks), block(kStreamBlock);
+  const dim3 block(kStreamBlock);
   if (fp.respawn) {
-    if (raw) hipLaunchKernelGGL((k_extend_finish<true, true>), grid, block, 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend_finish<true, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    if (raw) hipLaunchKernelGGL((k_extend_finish<true, true>), stream_grid(cfg, k_extend_finish<true, true>), block, 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend_finish<true, false>), stream_grid(cfg, k_extend_finish<true, false>), block, 0, cfg.stream, sc, st, fp);
   } else {
-    if (raw) hipLaunchKernelGGL((k_extend_finish<false, true>), grid, block, 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend_finish<false, false>), grid, block, 0, cfg.stream, sc, st, fp);
+    if (raw) hipLaunchKernelGGL((k_extend_finish<false, true>), stream_grid(cfg, k_extend_finish<false, true>), block, 0, cfg.stream, sc, st, fp);
+    else hipLaunchKernelGGL((k_extend_finish<false, false>), stream_grid(cfg, k_extend_finish<false, false>), block, 0, cfg.stream, sc, st, fp);
   }
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  if (fp.respawn) hipLaunchKernelGGL((k_finish_shade_uber<true>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_finish_shade_uber<false>), dim3(cfg.grid_blocks), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  if (fp.respawn) hipLaunchKernelGGL((k_finish_shade_uber<true>), stream_grid(cfg, k_finish_shade_uber<true>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_finish_shade_uber<false>), stream_grid(cfg, k_finish_shade_uber<false>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n) {
