@@ -189,7 +189,8 @@ def main():
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate": achieved / 6290.0,
+                    "traffic": traffic,
                     "note": "achieved = reference-layout bytes of the visits made (64 B per node, 160 B per triangle "
                             "test, 76 B per instance visit, 112 B per ray) over the kernel time; the walk re-reads a "
                             "scene that sits in L2 and Infinity Cache, so this exceeds what HBM could deliver; "
@@ -201,6 +202,10 @@ def main():
                     "node_steps_per_s": (counts.tlas_nodes + counts.blas_nodes) / max(st.extend_launches, 1) / (ext_ms * 1e-3)
                     if ext_ms > 0 else 0.0,
                     "gather_ceiling_per_s": 178.3e9,
+                    # every kernel of this rank in the same traffic model: extend visits + 340 B per shade event +
+                    # 236 B per spawned sample, over the wall time of the timed steps
+                    "algorithmic_GBs_all_kernels_per_gpu": (alg_bytes + 340.0 * st.shade_events + 236.0 * st.spawned_samples)
+                    / elapsed / 1e9,
                     "launches": int(st.extend_launches),
                     "per_ray": {"tlas_nodes": counts.tlas_nodes / max(counts.rays, 1),
                                 "instance_visits": counts.instance_visits / max(counts.rays, 1),
