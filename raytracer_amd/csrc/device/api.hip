@@ -37,6 +37,7 @@ struct mirt_ctx {
 
   // scene
   bool have_scene = false;
+  bool have_classic_tables = false;  // the scene came with classic_refs (per-material shading can run)
   DScene sc{};
   std::vector<void *> scene_allocs;     // geometry: nodes + triangles, normals
   std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
@@ -214,6 +215,7 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
     }
   }
   if (!walk_terminates(d->tlas_nodes, d->n_tlas_nodes)) return bad("TLAS links form a cycle");
+  if (d->n_light_sources != 0 && !d->light_sources) return bad("light_sources is null");
   const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
   if (!no_lights)
     for (uint32_t i = 0; i < d->n_light_sources; ++i)
@@ -254,12 +256,20 @@ bool validate_geometry(const MirtSceneDesc *d, std::string &why) {
     const uint32_t nn = node_end - o.blas_node, ni = idx_end - o.index, nv = vtx_end - o.vertex;
     if (nn > kMaxNodesPerTree) return bad("a BLAS has more than 2^24 nodes");
     if (ni > kMaxNodesPerTree) return bad("a geometry has more than 2^24 triangles");
+    if (ni == 0) return bad("a geometry has no triangles");
+    // Leaves must not share triangles: the first triangle of a big leaf carries
+    // that leaf's size and the offsets of its scan blocks and LDS image.
+    std::vector<uint8_t> in_leaf(ni, 0);
     for (uint32_t i = 0; i < nn; ++i) {
       const MirtBVHNode &n = d->blas_nodes[o.blas_node + i];
       if (n.right >= nn) return bad("BLAS skip link out of range");
       if (n.is_leaf > 1) return bad("BLAS is_leaf must be 0 or 1");
       if (n.is_leaf) {
         if (n.start >= n.end || n.end > ni) return bad("BLAS leaf empty or out of range");
+        for (uint32_t p = n.start; p < n.end; ++p) {
+          if (in_leaf[p]) return bad("BLAS leaves overlap");
+          in_leaf[p] = 1;
+        }
       } else if (n.left >= nn || n.left == 0) {
         return bad("BLAS child link out of range");
       }
@@ -533,10 +543,14 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     ctx->geom_node_base[g] = (uint32_t)nodes.size();
     ctx->geom_tri_base[g] = o.index;
     // light sampling draws from the primitive range of the BLAS root
-    // (archive/light.slang:60-64); for an inner root that is all triangles
+    // (archive/light.slang:60-64).  start/end of an inner node mean nothing
+    // (src/bvh.rs:206) and are not validated, so an inner root stands for every
+    // triangle of its geometry — which is what the reference's builder leaves
+    // in them (src/bvh.rs:144-151); a leaf root's range has been validated.
     const MirtBVHNode &root = d->blas_nodes[o.blas_node];
-    ctx->geom_root_start[g] = root.start;
-    ctx->geom_root_count[g] = root.end - root.start;
+    const uint32_t idx_end_g = last ? d->n_indices : d->geometry_offsets[g + 1].index;
+    ctx->geom_root_start[g] = root.is_leaf == 1 ? root.start : 0u;
+    ctx->geom_root_count[g] = root.is_leaf == 1 ? root.end - root.start : idx_end_g - o.index;
     const size_t at = nodes.size();
     nodes.resize(at + nn);
     std::vector<uint32_t> sizes(nn);
@@ -762,6 +776,7 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
   ctx->sc = sc;
   ctx->n_instances = d->n_instances;
   ctx->n_geometries = d->n_geometries;
+  ctx->have_classic_tables = d->n_classic_refs != 0;
   ctx->have_scene = true;
   return MIRT_OK;
 }
@@ -782,6 +797,7 @@ int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
   if (rc != MIRT_OK) return rc;
   ctx->sc = sc;
   ctx->n_instances = d->n_instances;
+  ctx->have_classic_tables = d->n_classic_refs != 0;
   ctx->have_scene = true;
   return MIRT_OK;
 }
@@ -870,7 +886,7 @@ static int check_ready(mirt_ctx *ctx) {
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state created");
   if (!ctx->have_camera) return fail(ctx, MIRT_ERR_NOT_READY, "no camera set");
-  if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && ctx->sc.lambertian == nullptr)
+  if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && !ctx->have_classic_tables)
     return fail(ctx, MIRT_ERR_NOT_READY, "classic shading needs the per-material tables");
   return MIRT_OK;
 }

@@ -710,16 +710,24 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
 constexpr int kEngineBlocksPerCU = (MIRT_ENGINE_WAVES * 256) / (int)kEngineBlock > 0 ? (MIRT_ENGINE_WAVES * 256) / (int)kEngineBlock : 1;
 
 int trace_grid_blocks(int num_cus) {
-  static int per_cu = 0;
-  if (per_cu == 0) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, (int)kEngineBlock, 0) != hipSuccess || n < 1) n = 4;
+  // Resident blocks per CU of the engine kernel with the most registers, asked
+  // once per device (the members of a group call this from one host thread each).
+  static std::mutex mu;
+  static std::unordered_map<int, int> per_device;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = per_device.find(dev);
+  if (it == per_device.end()) {
+    int n = 0, m = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_extend<false>, (int)kEngineBlock, 0) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k_trace<true, true>, (int)kEngineBlock, 0) == hipSuccess && m >= 1 && m < n) n = m;
     // Four to five waves per SIMD are enough to keep the memory path busy; more
     // resident waves only mean fewer rays per wave and a longer drain, so the
     // grid stops at kEngineBlocksPerCU blocks per CU.
-    per_cu = n > kEngineBlocksPerCU ? kEngineBlocksPerCU : n;
+    it = per_device.emplace(dev, n > kEngineBlocksPerCU ? kEngineBlocksPerCU : n).first;
   }
-  return per_cu * num_cus;
+  return it->second * num_cus;
 }
 
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

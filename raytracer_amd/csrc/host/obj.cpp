@@ -46,6 +46,23 @@ bool parse_float(const char *&p, const char *e, float &out) {
   return endp != buf;
 }
 
+// A decimal integer with an optional sign, read without looking at or past `e`
+// (the text need not end in a NUL or a newline).  False when no digit is there.
+bool parse_long(const char *&p, const char *e, long &out) {
+  const char *c = p;
+  bool neg = false;
+  if (c < e && (*c == '-' || *c == '+')) neg = *c++ == '-';
+  if (c >= e || *c < '0' || *c > '9') return false;
+  long v = 0;
+  while (c < e && *c >= '0' && *c <= '9') {
+    if (v > (0x7FFFFFFFL - 9) / 10) return false;  // no mesh has 2^31 vertices
+    v = v * 10 + (*c++ - '0');
+  }
+  out = neg ? -v : v;
+  p = c;
+  return true;
+}
+
 // Resolve a 1-based / negative OBJ index against a list of `count` items.
 bool resolve(long raw, size_t count, long &out) {
   if (raw > 0) {
@@ -114,14 +131,12 @@ bool parse_obj_first_model(const char *text, size_t len, ObjModel &out, std::str
                 if (field > 2) break;
                 continue;
               }
-              char *endp = nullptr;
-              long val = strtol(c, &endp, 10);
-              if (endp == c) {
+              long val = 0;
+              if (!parse_long(c, eol, val)) {
                 err = "bad face index at line " + std::to_string(line_no);
                 return false;
               }
               raw[field] = val;
-              c = endp;
             }
             if (!resolve(raw[0], pos.size() / 3, k.v)) {
               err = "face vertex out of bounds at line " + std::to_string(line_no);

@@ -153,6 +153,44 @@ def test_per_material_kernels_and_connect_rays_config5_small(pt, config_scenes):
     assert ffi.MAT_METALLIC in arrays2["classic_refs"]["kind"].tolist()
 
 
+def test_light_geometry_with_an_inner_root_ignores_its_meaningless_range(pt):
+    # start/end of an inner node mean nothing (src/bvh.rs:206): a light whose BLAS
+    # root is an inner node is sampled over all triangles of its geometry, whatever
+    # a client leaves in those two fields
+    s = host.Scene()
+    cube, rect = s.load_cube(), s.load_rect()
+    lamp = s.add_material(host.make_material(colour=(1, 1, 1, 1), emissive=(15, 15, 15, 1)))
+    grey = s.add_material(host.make_material(colour=(0.7, 0.7, 0.7, 1.0)))
+    s.spawn(host.make_transform(scale=(0.4, 0.1, 0.4), translation=(0.0, 1.2, 3.0)), lamp, cube)
+    s.spawn(host.make_transform(scale=(3, 3, 3), rotation=(np.pi / 2, 0, 0), translation=(0.0, -1.0, 3.0)), grey, rect)
+    s.spawn(host.make_transform(scale=(0.5, 0.5, 0.5), translation=(0.3, -0.4, 3.0)), grey, cube)
+    arrays = s.bind()
+    s.close()
+    assert arrays["light_sources"].tolist() == [0]
+    g = arrays["geometry_offsets"][arrays["instances"]["geometry"][0]]
+    root = int(g["blas_node"])
+    assert arrays["blas_nodes"]["is_leaf"][root] == 0  # twelve triangles: the root was split
+    W, H = 96, 64
+    src = host.make_sample_sources(W, H, 9)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=4, seed=9, shade_mode=1, nee=1)
+    oprm = po.default_params(max_bounces=4, seed=9, shade_mode=1, nee=1)
+    w4, wcnt, wst = po.Scene(arrays).render(cam, src, W, H, oprm, 0, 2)
+    assert wst.connect_rays > 1000
+    for start, end in ((0, 0), (0xFFFFFFF0, 7)):
+        odd = {k: v.copy() for k, v in arrays.items()}
+        odd["blas_nodes"]["start"][root] = start
+        odd["blas_nodes"]["end"][root] = end
+        pt.upload_scene(odd)
+        pt.create_state(W, H, 3000, src, prm)
+        pt.set_camera(cam)
+        pt.render_spp(2)
+        s4, cnt = pt.read_accum()
+        assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+        o4, ocnt, _ = po.Scene(odd).render(cam, src, W, H, oprm, 0, 2)
+        assert np.array_equal(o4, w4) and np.array_equal(ocnt, wcnt)
+
+
 def test_shadow_ray_sets_any_hit_ids(pt, config_scenes):
     # the connect (shadow) rays of configuration 5's scene at bounces 1 and 2, as
     # the oracle's per-material path generates them, traced as any-hit queries:
@@ -271,12 +309,28 @@ def test_errors_are_reported_not_thrown(pt, config_scenes):
     bad["instances"]["material"][0] = 7
     with pytest.raises(pathtracer.MirtError):
         pt.upload_scene(bad)
+    # two leaves over the same triangles (they would overwrite each other's per-leaf words)
+    bad = {k: v.copy() for k, v in arrays.items()}
+    leaves = np.flatnonzero(bad["blas_nodes"]["is_leaf"] == 1)
+    bad["blas_nodes"]["start"][leaves[1]] = bad["blas_nodes"]["start"][leaves[0]]
+    bad["blas_nodes"]["end"][leaves[1]] = bad["blas_nodes"]["end"][leaves[0]]
+    with pytest.raises(pathtracer.MirtError, match="overlap"):
+        pt.upload_scene(bad)
     fresh = pathtracer.Pathtracer(0)
     with pytest.raises(pathtracer.MirtError, match="no scene"):
         fresh.trace_closest(random_rays(4, 1))
     fresh.upload_scene(arrays)
     with pytest.raises(pathtracer.MirtError, match="state"):
         fresh.render_spp(1)
+    # per-material shading on a scene uploaded without its per-material tables
+    bare = {k: v for k, v in arrays.items() if k not in ("classic_refs", "lambertian", "metallic", "dielectric", "emissive")}
+    fresh.upload_scene(bare)
+    ok_src = host.make_sample_sources(8, 8, 1)
+    fresh.create_state(8, 8, 64, ok_src, pathtracer.default_params(max_bounces=2, shade_mode=1))
+    fresh.set_camera(host.default_camera(8, 8))
+    with pytest.raises(pathtracer.MirtError, match="per-material tables"):
+        fresh.render_spp(1)
+    fresh.upload_scene(arrays)
     src = host.make_sample_sources(8, 8, 1)
     src["out_pos"][0] = (99, 0)
     with pytest.raises(pathtracer.MirtError, match="outside"):

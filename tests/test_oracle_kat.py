@@ -967,6 +967,13 @@ f 1//1 2//1 6//1
     assert ffi.host_lib().mirth_parse_obj_counts(bad, len(bad), n_pos, n_nrm, n_tri) != 0
     empty = b"v 0 0 0\n"
     assert ffi.host_lib().mirth_parse_obj_counts(empty, len(empty), n_pos, n_nrm, n_tri) != 0
+    # a file whose last line is a face ending in a digit, with no newline and no NUL behind it:
+    # the reader is handed (pointer, length) into the middle of a larger buffer whose next bytes
+    # are digits, which an unbounded integer parse would swallow
+    tail = b"v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3"
+    arena = ffi.C.create_string_buffer(tail + b"99999\n", len(tail) + 6)
+    assert ffi.host_lib().mirth_parse_obj_counts(arena, len(tail), n_pos, n_nrm, n_tri) == 0
+    assert (n_pos.value, n_nrm.value, n_tri.value) == (3, 0, 1)
 
 
 def test_binder_packing_rules(config_scenes):
