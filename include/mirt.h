@@ -325,6 +325,19 @@ int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4,
 int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                        MirtHitId *out, MirtTraversalCounts *counts);
 
+/* mirt_trace_closest for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): same arguments and results, but the device-side staging (rays,
+ * results, visit counters, the launch's work cursor) lives in a fixed
+ * file-scope device array of the library — 6 MiB + 256 B, held by every GPU the
+ * library runs on until the process ends — instead of being allocated per call.
+ * At most 131072 rays per call; more is MIRT_ERR_INVALID_ARGUMENT.  Calls no
+ * hipMalloc / hipFree.  Every call on a GPU shares that GPU's array: calls that
+ * overlap on one GPU (two contexts, two threads) race and must be serialised by
+ * the caller.  No counterpart in the reference. */
+int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n,
+                              MirtHitId *out, MirtTraversalCounts *counts);
+
 /* Any hit with t in [0, tmax[i]] (shadow / connect query, the role
  * shaders/ray_connect.slang:1-7 describes).  out[i] is the FIRST triangle the
  * threaded traversal accepts (instance_id 0xFFFFFFFF when unoccluded). */

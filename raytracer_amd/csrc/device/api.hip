@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <memory>
+#include <mutex>
 #include <new>
 #include <algorithm>
 #include <string>
@@ -18,7 +19,38 @@
 
 using namespace mirt;
 
+// ---- the workspace of mirt_trace_closest_static: one file-scope array per
+// device, so that the call allocates nothing.  Layout: 256 bytes of counters
+// (five visit counters, the launch's chunk cursor), then kStaticTraceMaxRays
+// rays (32 B each), then as many results (16 B each).
+constexpr size_t kStaticTraceMaxRays = 131072;
+constexpr size_t kStaticTraceRayOff = 256;
+constexpr size_t kStaticTraceOutOff = kStaticTraceRayOff + kStaticTraceMaxRays * sizeof(MirtRay);
+constexpr size_t kStaticTraceBytes = kStaticTraceOutOff + kStaticTraceMaxRays * sizeof(MirtHitId);
+static __device__ __align__(256) unsigned char scratch[kStaticTraceBytes];
+
 namespace {
+
+// `scratch` names a host-side stand-in; the array's address on a device comes
+// from hipGetSymbolAddress with that device current, once per device.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+
+// With `device` current.  Returns nullptr when the address cannot be had.
+unsigned char *static_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+  }
+  return g_scratch_ptr[device];
+}
 
 struct EventPair {
   hipEvent_t a, b;
@@ -65,6 +97,7 @@ struct mirt_ctx {
   uint64_t frames_total = 0;
   unsigned long long *h_stats = nullptr;  // pinned, S_COUNT + Q_COUNT words
   unsigned long long *d_trace_counts = nullptr;
+  unsigned char *static_ws = nullptr;  // this device's copy of the file-scope workspace (mirt_trace_closest_static)
   void *build_ws = nullptr;  // workspace of mirt_build_blas, grown on demand
   size_t build_ws_bytes = 0;
 };
@@ -483,6 +516,7 @@ int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
     delete c;
     return MIRT_ERR_OUT_OF_MEMORY;
   }
+  c->static_ws = static_scratch(device_ordinal);  // a failure is reported by the entry point that needs it
   mirt_default_params(&c->params);
   *out_ctx = c;
   return MIRT_OK;
@@ -1055,6 +1089,46 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
 int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out, MirtTraversalCounts *counts) {
   ENTER(ctx);
   return trace_common(ctx, rays, nullptr, n, out, counts, false, 0, nullptr);
+}
+
+int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out,
+                              MirtTraversalCounts *counts) {
+  ENTER(ctx);
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  if (n == 0) return MIRT_OK;
+  if (!rays || !out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: null pointer");
+  if (n > kStaticTraceMaxRays)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT,
+                "trace_closest_static: at most " + std::to_string(kStaticTraceMaxRays) +
+                    " rays per call (the workspace is a fixed array); split the set or use mirt_trace_closest");
+  for (size_t i = 0; i < n; ++i)
+    if (rays[i].last_inst != 0x7FFFFFFFu && rays[i].last_inst >= ctx->n_instances && rays[i].last_inst != 0xFFFFFFFFu)
+      return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "trace: last_inst out of range");
+  unsigned char *ws = ctx->static_ws;
+  if (!ws) return fail(ctx, MIRT_ERR_HIP, "trace_closest_static: the address of the static workspace is not available on this device");
+  unsigned long long *d_counts = reinterpret_cast<unsigned long long *>(ws);
+  uint32_t *work = reinterpret_cast<uint32_t *>(d_counts + 5);
+  DRay *d_rays = reinterpret_cast<DRay *>(ws + kStaticTraceRayOff);
+  MirtHitId *d_out = reinterpret_cast<MirtHitId *>(ws + kStaticTraceOutOff);
+  // the array keeps the last call's contents: counters and cursor start at zero,
+  // rays and results of this call overwrite the first n records
+  HIP_TRY(ctx, hipMemsetAsync(ws, 0, kStaticTraceRayOff, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_rays, rays, n * sizeof(MirtRay), hipMemcpyHostToDevice, ctx->stream));
+  LaunchCfg cfg;
+  cfg.stream = ctx->stream;
+  cfg.grid_blocks = ctx->num_cus * 2;
+  cfg.num_cus = ctx->num_cus;
+  launch_trace(cfg, ctx->sc, d_rays, nullptr, n, d_out, d_counts, work, false, counts != nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * sizeof(MirtHitId), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long h[5] = {0, 0, 0, 0, 0};
+  if (counts) HIP_TRY(ctx, hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (counts) {
+    counts->rays = h[0]; counts->tlas_nodes = h[1]; counts->instance_visits = h[2];
+    counts->blas_nodes = h[3]; counts->triangles = h[4];
+  }
+  return MIRT_OK;
 }
 
 int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, size_t n, MirtHitId *out,

@@ -215,7 +215,7 @@ DEVICE_SYMBOLS = [
     "mirt_scene_upload", "mirt_scene_update_instances", "mirt_state_create", "mirt_camera_set", "mirt_reset_accum",
     "mirt_set_sample_range", "mirt_step", "mirt_render_spp", "mirt_synchronize", "mirt_read_output",
     "mirt_read_accum", "mirt_copy_accum_to_device", "mirt_load_accum_from_device",
-    "mirt_trace_closest", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_stats",
+    "mirt_trace_closest", "mirt_trace_closest_static", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_stats",
     "mirt_stats_reset", "mirt_set_counting", "mirt_set_event_timing", "mirt_dump_extension_rays",
     "mirt_math_selftest", "mirt_build_blas",
     "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_member", "mirt_group_last_error",
@@ -254,6 +254,7 @@ def device_lib():
         L.mirt_copy_accum_to_device.argtypes = [vp, vp, vp, sz]
         L.mirt_load_accum_from_device.argtypes = [vp, vp, vp, sz]
         L.mirt_trace_closest.argtypes = [vp, vp, sz, vp, C.POINTER(TraversalCounts)]
+        L.mirt_trace_closest_static.argtypes = [vp, vp, sz, vp, C.POINTER(TraversalCounts)]
         L.mirt_trace_any.argtypes = [vp, vp, vp, sz, vp, C.POINTER(TraversalCounts)]
         L.mirt_bench_trace_closest.argtypes = [vp, vp, sz, u32, C.POINTER(C.c_double)]
         L.mirt_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -129,6 +129,15 @@ class Pathtracer:
                                                C.byref(c) if want_counts else None), "mirt_trace_closest")
         return (out, c) if want_counts else out
 
+    def trace_closest_static(self, rays, want_counts=False):
+        """mirt_trace_closest_static: the same query staged in the library's fixed device array (no allocation)."""
+        rays = np.ascontiguousarray(rays, ffi.Ray)
+        out = np.zeros(len(rays), ffi.HitId)
+        c = ffi.TraversalCounts()
+        self._check(self._L.mirt_trace_closest_static(self._h, rays.ctypes.data, len(rays), out.ctypes.data,
+                                                      C.byref(c) if want_counts else None), "mirt_trace_closest_static")
+        return (out, c) if want_counts else out
+
     def trace_any(self, rays, tmax, want_counts=False):
         rays = np.ascontiguousarray(rays, ffi.Ray)
         tmax = np.ascontiguousarray(tmax, "<f4")
