@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--paths-per-pixel", type=int, default=32,
                     help="paths in flight (slots of the wavefront state) per pixel")
     ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--mode", choices=["render", "step"], default="render",
+                    help="render: mirt_render_spp passes (the headline); step: mirt_step, one call per frame, at the "
+                         "reference's operating point (512x512, one path slot per pixel, src/pathtracer.rs:34-38)")
+    ap.add_argument("--frames-per-step", type=int, default=64, help="step mode: frames per bench step")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +91,141 @@ def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
             "sample": f"first {n2} of {len(src)} sample sources of the same workload, {spp} spp, {rays} rays in {dt:.2f} s"}
 
 
+DEVICE_SOURCES = ["engine.h", "kernels.hip", "kernels.h", "layout.h", "device_util.h", "rt_math.h", "classic.hip", "api.hip"]
+
+
+def device_sources_sha():
+    """Hash of the sources the traversal and frame kernels are built from: a counter figure
+    taken from profiles/ is only used when it was measured on these very sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in DEVICE_SOURCES:
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", "device", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
+    """What bounds the extend kernel, from this run's own measurements.
+
+    The walk is a per-lane chain of dependent small fetches; the scene sits in L2 + Infinity
+    Cache, so the binding resource is the rate at which the memory pipeline serves such
+    gathers, not HBM.  achieved = bytes the lanes actually request per launch (32 B per node
+    visit, 48 B per triangle fetched by a lane, 36 B per triangle of a whole-wave scan read
+    from memory, 68 B per instance visit, 48 B per ray in and out) / the kernel's mean launch
+    time (HIP events on its stream); peak = 32 B x the lane-steps/s of dependent 32-byte
+    gathers from a table of this scene's size, measured now, untimed, with the same block
+    shape.  Triangle tests served from the LDS leaf cache move no memory and are listed apart.
+    hbm_frac = memory-side bytes per launch from the PMC counters (profiles/traffic.json, used
+    only when it was taken on these sources) / launch time / 8 TB/s."""
+    launches = max(int(st.extend_launches), 1)
+    ext_s = st.extend_ms * 1e-3 / launches
+    c = cst.extend_counts
+    nodes = c.tlas_nodes + c.blas_nodes
+    tri_lds, tri_scan = int(cst.extend_tri_wave_lds), int(cst.extend_tri_wave_mem)
+    tri_lane = int(c.triangles) - tri_lds - tri_scan
+    requested = 32 * nodes + 48 * tri_lane + 36 * tri_scan + 68 * c.instance_visits + 48 * c.rays
+    scene_bytes, cache_bytes = pt.scene_bytes()
+    gather_rate = pt.bench_gather(0, 512, 3)          # lane-steps/s, table = this scene's nodes + triangles
+    gather_rate_l2 = pt.bench_gather(2 << 20, 512, 3)  # the same from a table that fits one XCD's L2
+    achieved = requested / launches / ext_s / 1e9 if ext_s > 0 else 0.0
+    peak = gather_rate * 32 / 1e9
+    alg_bytes = c.algorithmic_bytes(112)
+    traffic = traffic_src = None
+    try:
+        tj = json.load(open(args.traffic_json))
+        if (tj.get("workload") == workload and tj.get("paths_in_flight") == n_paths
+                and tj.get("device_sources_sha") == device_sources_sha()):
+            traffic = tj.get("memory_side_bytes_per_extend_launch")
+            traffic_src = {k: tj.get(k) for k in ("measured_at_head", "fetch_size_bytes", "write_size_bytes",
+                                                  "fetch_calibration")}
+    except Exception:
+        traffic = None
+    per_ray = {"tlas_nodes": c.tlas_nodes / max(c.rays, 1), "instance_visits": c.instance_visits / max(c.rays, 1),
+               "blas_nodes": c.blas_nodes / max(c.rays, 1), "triangles": c.triangles / max(c.rays, 1),
+               "triangles_fetched_by_a_lane": tri_lane / max(c.rays, 1),
+               "triangles_in_whole_wave_scans_from_lds": tri_lds / max(c.rays, 1),
+               "triangles_in_whole_wave_scans_from_memory": tri_scan / max(c.rays, 1)}
+    return {
+        "bound": "hbm", "kernel": "k_extend", "unit": "GB/s",
+        "binding_resource": "dependent per-lane gathers through L1 miss path / L2 / Infinity Cache (scene resident on die)",
+        "achieved": achieved, "peak": peak, "frac": achieved / peak if peak > 0 else None,
+        "peak_source": f"mirt_bench_gather in this process: {gather_rate / 1e9:.1f} G lane-steps/s x 32 B, "
+                       f"table {scene_bytes / 1e6:.1f} MB = this scene's nodes + triangles",
+        "frac_of_l2_resident_gather_rate": achieved / (gather_rate_l2 * 32 / 1e9) if gather_rate_l2 > 0 else None,
+        "gather_lane_steps_per_s": {"scene_sized_table": gather_rate, "2MiB_table": gather_rate_l2},
+        "requested_bytes_per_launch": requested / launches,
+        "lds_served_triangle_tests_per_launch": tri_lds / launches,
+        "lds_served_bytes_equivalent_per_launch": 48 * tri_lds / launches,
+        "launch_ms": ext_s * 1e3, "launches": launches,
+        "traffic": traffic, "traffic_source": traffic_src,
+        "hbm_peak": HBM_PEAK_GBS,
+        "hbm_frac": (traffic / ext_s / 1e9 / HBM_PEAK_GBS) if traffic and ext_s > 0 else None,
+        # the traffic model in the reference's struct sizes (64 B per node, 160 B per triangle test, 76 B per
+        # instance visit, 112 B per ray): a throughput figure in the reference's units, NOT memory traffic
+        "algorithmic_GBs_reference_layout": alg_bytes / launches / ext_s / 1e9 if ext_s > 0 else 0.0,
+        "algorithmic_GBs_reference_layout_all_kernels": (alg_bytes + 340.0 * st.shade_events + 236.0 * st.spawned_samples)
+        / elapsed / 1e9,
+        "node_steps_per_s": nodes / launches / ext_s if ext_s > 0 else 0.0,
+        "per_ray": per_ray,
+    }
+
+
+def step_mode(args, pt, info, W, H, src, cam, params, world):
+    """The drop-in's own operating point: one mirt_step(1) per frame, as the reference's
+    pathtracer_phase_execute submits four dispatches per frame (src/pathtracer_manager.rs:74-124),
+    with T = W*H path slots (src/pathtracer.rs:34-38).  A bench step is --frames-per-step frames."""
+    import torch
+    n_paths = W * H  # Pathtracer.threads = dims.0 * dims.1
+    pt.create_state(W, H, n_paths, src, params)
+    pt.set_camera(cam)
+    F = args.frames_per_step
+    for _ in range(args.warmup):
+        for _ in range(F):
+            pt.step(1)
+    pt.synchronize()
+    pt.stats_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for _ in range(F):
+            pt.step(1)
+    pt.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = pt.stats()
+    rays = int(st.extend_rays + st.connect_rays)
+    frames = int(st.frames)
+    # the kernels' own time per frame, from HIP events on the library's stream, in a second untimed pass
+    pt.stats_reset()
+    pt.set_event_timing(True)
+    for _ in range(F):
+        pt.step(1)
+    pt.synchronize()
+    pt.set_event_timing(False)
+    ev = pt.stats()
+    kernel_ms_per_frame = (ev.extend_ms + ev.finish_ms + ev.shade_ms + ev.sample_ms + ev.connect_ms) / max(int(ev.frames), 1)
+    wall_ms_per_frame = elapsed / max(frames, 1) * 1e3
+    geometry = "procedural dragon-class knot, 871040 triangles" if info.procedural_dragon else "dragon asset"
+    out = {
+        "metric": "Mrays/s (extend+shadow), per-frame stepping", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, {info.max_bounces} bounces, "
+                               f"mirt_step(1) per frame, {F} frames per step, "
+                               f"{'per-material' if info.shade_mode else 'uber'} shading",
+                   "geometry": geometry, "paths_in_flight": n_paths, "parallelism": "one GPU"},
+        "frames_per_s": frames / elapsed, "wall_ms_per_frame": wall_ms_per_frame,
+        "kernel_ms_per_frame": kernel_ms_per_frame,
+        "host_and_launch_overhead_us_per_frame": (wall_ms_per_frame - kernel_ms_per_frame) * 1e3,
+        "kernel_ms_per_frame_by_kernel": {"extend": ev.extend_ms / max(int(ev.frames), 1), "shade": ev.shade_ms / max(int(ev.frames), 1),
+                                          "sample": ev.sample_ms / max(int(ev.frames), 1),
+                                          "extend_finish": ev.finish_ms / max(int(ev.frames), 1),
+                                          "connect": ev.connect_ms / max(int(ev.frames), 1)},
+        "spp_per_s": int(st.finished_samples) / (W * H) / elapsed, "rays": rays,
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -115,8 +254,16 @@ def main():
     cam = host.default_camera(W, H)
     params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
                                        nee=info.nee)
+    if args.mode == "step":
+        W, H = args.width or 512, args.height or 512
+        src = host.make_sample_sources(W, H, info.seed, shuffle=2)
+        cam = host.default_camera(W, H)
     pt = pathtracer.Pathtracer(local_rank)
     pt.upload_scene(arrays)
+    if args.mode == "step":
+        step_mode(args, pt, info, W, H, src, cam, params, world)
+        pt.close()
+        return
     n_paths = W * H * args.paths_per_pixel
     pt.create_state(W, H, n_paths, src, params)
     pt.set_camera(cam)
@@ -167,7 +314,6 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: replay the timed samples with visit counting
-        ext_ms = st.extend_ms / max(st.extend_launches, 1)
         pt.stats_reset()
         pt.set_counting(True)
         pt.set_sample_range(first + args.warmup * spp_step)
@@ -175,42 +321,8 @@ def main():
             pt.render_spp(spp_step)
         pt.set_counting(False)
         cst = pt.stats()
-        counts = cst.extend_counts
-        assert counts.rays == st.extend_rays, (counts.rays, st.extend_rays)
-        alg_bytes = counts.algorithmic_bytes(112)  # 112 B fixed per ray + 64 B/node + 76 B/instance visit + 160 B/triangle
-        per_launch = alg_bytes / max(st.extend_launches, 1)
-        achieved = per_launch / (ext_ms * 1e-3) / 1e9 if ext_ms > 0 else 0.0
-        traffic = None
-        if os.path.exists(args.traffic_json):
-            try:
-                tj = json.load(open(args.traffic_json))
-                if tj.get("workload") == f"config{args.config} {W}x{H}" and tj.get("paths_in_flight") == n_paths:
-                    traffic = tj.get("hbm_bytes_per_extend_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_rate": achieved / 6290.0,
-                    "traffic": traffic,
-                    "note": "achieved = reference-layout bytes of the visits made (64 B per node, 160 B per triangle "
-                            "test, 76 B per instance visit, 112 B per ray) over the kernel time; the walk re-reads a "
-                            "scene that sits in L2 and Infinity Cache, so this exceeds what HBM could deliver; "
-                            "traffic = measured memory-side bytes per launch",
-                    "algorithmic_bytes_per_launch": per_launch, "launch_ms": ext_ms,
-                    # the stage that does bind: node fetches per second against the gather rate the
-                    # memory pipeline sustains for 32-B records of a table this size
-                    # (profiles/r01_gather_microbench.txt, 64 MB table, any occupancy)
-                    "node_steps_per_s": (counts.tlas_nodes + counts.blas_nodes) / max(st.extend_launches, 1) / (ext_ms * 1e-3)
-                    if ext_ms > 0 else 0.0,
-                    "gather_ceiling_per_s": 178.3e9,
-                    # every kernel of this rank in the same traffic model: extend visits + 340 B per shade event +
-                    # 236 B per spawned sample, over the wall time of the timed steps
-                    "algorithmic_GBs_all_kernels_per_gpu": (alg_bytes + 340.0 * st.shade_events + 236.0 * st.spawned_samples)
-                    / elapsed / 1e9,
-                    "launches": int(st.extend_launches),
-                    "per_ray": {"tlas_nodes": counts.tlas_nodes / max(counts.rays, 1),
-                                "instance_visits": counts.instance_visits / max(counts.rays, 1),
-                                "blas_nodes": counts.blas_nodes / max(counts.rays, 1),
-                                "triangles": counts.triangles / max(counts.rays, 1)}}
+        assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
+        roofline = extend_roofline(pt, st, cst, elapsed, args, f"config{args.config} {W}x{H}", n_paths)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)

@@ -235,6 +235,17 @@ typedef struct MirtStats {
   uint64_t sample_launches;   double sample_ms;
   MirtTraversalCounts extend_counts;  /* filled only when counting is enabled */
   MirtTraversalCounts connect_counts;
+  /* of extend_counts.triangles / connect_counts.triangles: the tests made in
+   * whole-wave scans of big leaves, split by where the scan read the triangles
+   * (the LDS leaf cache: no memory traffic; lane-interleaved blocks in memory,
+   * 36 B per triangle).  The remaining tests fetched one 48-B record each. */
+  uint64_t extend_tri_wave_lds, extend_tri_wave_mem;
+  uint64_t connect_tri_wave_lds, connect_tri_wave_mem;
+  /* adds that found a 32-bit radiance sum at its limit: the sum stays at
+   * 2^32 - 1 instead of wrapping as the reference's InterlockedAdd does
+   * (shaders/sample.slang:45-47).  Non-zero means the image is clipped there:
+   * render fewer samples per accumulator or lower fixed_point_scale. */
+  uint64_t overflowed_sums;
   /* diagnostic builds only (-DMIRT_PHASE_TIMING), summed over the waves of the
    * extend kernel: service points, lane node steps, lane triangle steps,
    * whole-wave leaves, shader-clock cycles, loop iterations, walking lanes summed
@@ -348,6 +359,21 @@ int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax,
  * (HIP events on the context's stream); returns the mean ms per launch. */
 int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                              uint32_t repeats, double *ms_per_launch);
+
+/* The ceiling the traversal kernels are measured against: lane-steps per
+ * second of per-lane dependent gathers of 32-byte records (the access pattern of
+ * a BVH walk and nothing else) from a table of `table_bytes` — 0 = the size of
+ * the uploaded scene's node + triangle array — with the traversal kernels' block
+ * shape; best of `repeats` launches of `steps` steps per lane.  Allocates the
+ * table for the duration of the call.  Diagnostic; no counterpart in the
+ * reference, which has no timing code (src/pathtracer_manager.rs:99). */
+int mirt_bench_gather(mirt_ctx *ctx, size_t table_bytes, uint32_t steps,
+                      uint32_t repeats, double *lane_steps_per_s);
+
+/* Bytes of the uploaded scene's node + triangle array (what a walk gathers
+ * from) and of its LDS leaf-cache image. */
+int mirt_scene_bytes(mirt_ctx *ctx, uint64_t *node_and_triangle_bytes,
+                     uint64_t *leaf_cache_bytes);
 
 /* ------------------------------------------------------------- BLAS build */
 

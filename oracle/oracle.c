@@ -662,23 +662,35 @@ static inline uint32_t to_fixed(float rad, float scale) {
   if (x >= 4294967040.0f) return 4294967040u;
   return (uint32_t)x;
 }
-static void accumulate_sample(const path *p, const MirtParams *prm, uint32_t *sum4, uint32_t *count) {
+/* The reference's InterlockedAdd wraps (shaders/sample.slang:45-47); here a sum
+ * that would pass 2^32 - 1 stays there, so that the result does not depend on
+ * the order of the adds, and the event is counted.  Returns 1 on saturation. */
+static int sat_add(uint32_t *p, uint32_t v) {
+  uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED), nv;
+  int sat;
+  do {
+    sat = old + v < old;
+    nv = sat ? 0xFFFFFFFFu : old + v;
+  } while (!__atomic_compare_exchange_n(p, &old, nv, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return sat;
+}
+static uint32_t accumulate_sample(const path *p, const MirtParams *prm, uint32_t *sum4, uint32_t *count) {
   const uint32_t fx = to_fixed(p->rad.x, prm->fixed_point_scale);
   const uint32_t fy = to_fixed(p->rad.y, prm->fixed_point_scale);
   const uint32_t fz = to_fixed(p->rad.z, prm->fixed_point_scale);
 #pragma omp atomic
   count[p->source] += 1;
-#pragma omp atomic
-  sum4[4 * (size_t)p->source + 0] += fx;
-#pragma omp atomic
-  sum4[4 * (size_t)p->source + 1] += fy;
-#pragma omp atomic
-  sum4[4 * (size_t)p->source + 2] += fz;
+  uint32_t sat = 0;
+  sat += (uint32_t)sat_add(&sum4[4 * (size_t)p->source + 0], fx);
+  sat += (uint32_t)sat_add(&sum4[4 * (size_t)p->source + 1], fy);
+  sat += (uint32_t)sat_add(&sum4[4 * (size_t)p->source + 2], fz);
+  return sat;
 }
 
 static void stats_add(OracleRenderStats *dst, const OracleRenderStats *src) {
   dst->extend_rays += src->extend_rays; dst->connect_rays += src->connect_rays;
   dst->shade_events += src->shade_events; dst->finished_samples += src->finished_samples;
+  dst->overflowed_sums += src->overflowed_sums;
   dst->extend_counts.rays += src->extend_counts.rays;
   dst->extend_counts.tlas_nodes += src->extend_counts.tlas_nodes;
   dst->extend_counts.instance_visits += src->extend_counts.instance_visits;
@@ -731,7 +743,7 @@ void oracle_render(const oracle_scene *s, const MirtCamera *camera, const MirtSa
       spawn_sample(&p, camera, &sources[source], source, k, width, height, params);
       while (advance_path(s, &p, params, &st)) {
       }
-      accumulate_sample(&p, params, sum4, count);
+      st.overflowed_sums += accumulate_sample(&p, params, sum4, count);
       st.finished_samples++;
     }
 #pragma omp critical
@@ -749,11 +761,12 @@ static int queue_read(lifo *q) {
   return (int)q->data[idx];
 }
 
-void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
-                             const MirtSampleSource *sources, uint32_t n_sources, uint32_t width,
-                             uint32_t height, const MirtParams *params, uint32_t first_sample,
-                             uint32_t spp, uint32_t slots, uint32_t *sum4, uint32_t *count,
-                             OracleRenderStats *stats, uint64_t *frames_out) {
+/* `limit` samples are handed out at most; the loop ends when the queues are
+ * empty or after `max_frames` frames, whichever comes first. */
+static void wavefront_run(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                          uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                          uint32_t first_sample, uint64_t limit, uint64_t max_frames, uint32_t slots, uint32_t *sum4,
+                          uint32_t *count, OracleRenderStats *stats, uint64_t *frames_out) {
   OracleRenderStats st;
   memset(&st, 0, sizeof(st));
   path *paths = (path *)calloc(slots, sizeof(path));
@@ -765,14 +778,17 @@ void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
    * which credits `slots` bogus samples to source 0 (src/queue.rs:14-18,
    * shaders/sample.slang:38); here the first frame only spawns. */
   for (uint32_t i = 0; i < slots; ++i) queue_push(&term, i);
-  const uint64_t limit = (uint64_t)n_sources * spp;
   uint64_t sample_index = 0, frames = 0;
-  while (term.count > 0 || ext.count > 0 || shade.count > 0) {
+  while ((term.count > 0 || ext.count > 0 || shade.count > 0) && frames < max_frames) {
     /* sampleMain: every thread pops at most one slot */
     for (uint32_t th = 0; th < slots; ++th) {
       int idx = queue_read(&term);
       if (idx < 0) break;
-      if (live[idx]) { accumulate_sample(&paths[idx], params, sum4, count); st.finished_samples++; live[idx] = 0; }
+      if (live[idx]) {
+        st.overflowed_sums += accumulate_sample(&paths[idx], params, sum4, count);
+        st.finished_samples++;
+        live[idx] = 0;
+      }
       if (sample_index < limit) {
         uint64_t si = sample_index++;
         uint32_t source = (uint32_t)(si % n_sources), k = first_sample + (uint32_t)(si / n_sources);
@@ -806,6 +822,23 @@ void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
   if (frames_out) *frames_out = frames;
   if (stats) stats_add(stats, &st);
   free(paths); free(live); free(term.data); free(ext.data); free(shade.data);
+}
+
+void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
+                             const MirtSampleSource *sources, uint32_t n_sources, uint32_t width,
+                             uint32_t height, const MirtParams *params, uint32_t first_sample,
+                             uint32_t spp, uint32_t slots, uint32_t *sum4, uint32_t *count,
+                             OracleRenderStats *stats, uint64_t *frames_out) {
+  wavefront_run(s, camera, sources, n_sources, width, height, params, first_sample, (uint64_t)n_sources * spp,
+                ~(uint64_t)0, slots, sum4, count, stats, frames_out);
+}
+
+void oracle_step_wavefront(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                           uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                           uint32_t first_sample, uint64_t n_frames, uint32_t slots, uint32_t *sum4,
+                           uint32_t *count, OracleRenderStats *stats) {
+  wavefront_run(s, camera, sources, n_sources, width, height, params, first_sample, ~(uint64_t)0, n_frames, slots,
+                sum4, count, stats, NULL);
 }
 
 void oracle_bounce_rays(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,

@@ -46,6 +46,7 @@ void oracle_trace_brute(const oracle_scene *s, const MirtRay *rays, size_t n, Mi
 typedef struct OracleRenderStats {
   uint64_t extend_rays, connect_rays, shade_events, finished_samples;
   MirtTraversalCounts extend_counts, connect_counts;
+  uint64_t overflowed_sums; /* adds that found a radiance sum at its 32-bit limit (the sum stays there) */
 } OracleRenderStats;
 
 /* Render samples [first_sample, first_sample + spp) of every source, one whole
@@ -64,6 +65,14 @@ void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
                              uint32_t height, const MirtParams *params, uint32_t first_sample,
                              uint32_t spp, uint32_t slots, uint32_t *sum4, uint32_t *count,
                              OracleRenderStats *stats, uint64_t *frames);
+
+/* The first `n_frames` frames of the same simulation with samples that keep
+ * regenerating (no sample budget): what n_frames frames of the reference's
+ * per-frame dispatch (src/pathtracer_manager.rs:74-124) have accumulated. */
+void oracle_step_wavefront(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                           uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                           uint32_t first_sample, uint64_t n_frames, uint32_t slots, uint32_t *sum4,
+                           uint32_t *count, OracleRenderStats *stats);
 
 /* The extension rays of bounce `bounce` (0 = camera rays) of sample
  * `sample_no` of every source; out[i].last_inst == 0xFFFFFFFF marks a path

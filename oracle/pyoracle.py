@@ -17,7 +17,7 @@ _lib = None
 class RenderStats(C.Structure):
     _fields_ = [("extend_rays", C.c_uint64), ("connect_rays", C.c_uint64), ("shade_events", C.c_uint64),
                 ("finished_samples", C.c_uint64), ("extend_counts", ffi.TraversalCounts),
-                ("connect_counts", ffi.TraversalCounts)]
+                ("connect_counts", ffi.TraversalCounts), ("overflowed_sums", C.c_uint64)]
 
 
 def lib():
@@ -41,6 +41,8 @@ def lib():
                                     C.POINTER(RenderStats), C.c_int]
         L.oracle_render_wavefront.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, u32,
                                               vp, vp, C.POINTER(RenderStats), C.POINTER(C.c_uint64)]
+        L.oracle_step_wavefront.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, C.c_uint64, u32,
+                                            vp, vp, C.POINTER(RenderStats)]
         L.oracle_bounce_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp]
         L.oracle_connect_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp, vp]
         L.oracle_resolve.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), vp]
@@ -132,6 +134,17 @@ class Scene:
                                       C.byref(params), first_sample, spp, slots, sum4.ctypes.data,
                                       count.ctypes.data, C.byref(st), C.byref(frames))
         return sum4, count, st, frames.value
+
+    def step_wavefront(self, camera, sources, width, height, params, first_sample, n_frames, slots):
+        """Sums, counts and statistics after `n_frames` frames of the regenerating wavefront."""
+        n = len(sources)
+        sum4 = np.zeros(4 * n, "<u4")
+        count = np.zeros(n, "<u4")
+        st = RenderStats()
+        lib().oracle_step_wavefront(self._h, camera.ctypes.data, sources.ctypes.data, n, width, height,
+                                    C.byref(params), first_sample, n_frames, slots, sum4.ctypes.data,
+                                    count.ctypes.data, C.byref(st))
+        return sum4, count, st
 
     def bounce_rays(self, camera, sources, width, height, params, sample_no, bounce):
         out = np.zeros(len(sources), ffi.Ray)

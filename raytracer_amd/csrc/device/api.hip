@@ -1143,6 +1143,28 @@ int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, uint3
   return trace_common(ctx, rays, nullptr, n, nullptr, nullptr, false, repeats, ms_per_launch);
 }
 
+int mirt_bench_gather(mirt_ctx *ctx, size_t table_bytes, uint32_t steps, uint32_t repeats, double *lane_steps_per_s) {
+  ENTER(ctx);
+  if (!lane_steps_per_s) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bench_gather: null pointer");
+  if (table_bytes == 0) {
+    if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "bench_gather: table_bytes 0 means the scene's size, and no scene is uploaded");
+    table_bytes = ctx->sc.geo_bytes;
+  }
+  std::string err;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const int rc = gather_ceiling(ctx->stream, ctx->num_cus, table_bytes, steps, repeats, lane_steps_per_s, err);
+  if (rc != MIRT_OK) return fail(ctx, rc, err);
+  return MIRT_OK;
+}
+
+int mirt_scene_bytes(mirt_ctx *ctx, uint64_t *node_and_triangle_bytes, uint64_t *leaf_cache_bytes) {
+  ENTER(ctx);
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  if (node_and_triangle_bytes) *node_and_triangle_bytes = ctx->sc.geo_bytes;
+  if (leaf_cache_bytes) *leaf_cache_bytes = ctx->sc.leaf_cache_bytes;
+  return MIRT_OK;
+}
+
 int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
   ENTER(ctx);
   if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "stats: null pointer");
@@ -1166,6 +1188,11 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
     out->connect_counts.instance_visits = s[S_CON_INST];
     out->connect_counts.blas_nodes = s[S_CON_BLAS];
     out->connect_counts.triangles = s[S_CON_TRI];
+    out->extend_tri_wave_lds = s[S_EXT_TRI_LDS];
+    out->extend_tri_wave_mem = s[S_EXT_TRI_MEM];
+    out->connect_tri_wave_lds = s[S_CON_TRI_LDS];
+    out->connect_tri_wave_mem = s[S_CON_TRI_MEM];
+    out->overflowed_sums = s[S_OVERFLOW];
     for (int k = 0; k < 8; ++k) out->engine_phase[k] = s[S_PHASE0 + k];
   }
   out->frames = ctx->frames_total;

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kEngineBlock) void k_connect(DScene sc, DState st, 
   };
   trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
+  if (COUNT) flush_wave_scan_counts(st.stats, S_CON_TRI_LDS, lc);
   for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);
   if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
 }

@@ -160,6 +160,17 @@ __device__ __forceinline__ void store_rng(DPath *p, const Rng &rng) {
       make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
 }
 
+// The two whole-wave-scan tallies of a lane, to stats[first], stats[first + 1].
+__device__ __forceinline__ void flush_wave_scan_counts(unsigned long long *stats, int first, const LaneCounts &lc) {
+  const uint32_t v[2] = {lc.tri_wave_lds, lc.tri_wave_mem};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    unsigned long long s = v[k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane_id() == 0u && s) atomicAdd(&stats[first + k], s);
+  }
+}
+
 // One atomic per wave and counter.
 __device__ __forceinline__ void flush_counts(unsigned long long *stats, int first, const LaneCounts &lc) {
   const uint32_t v[4] = {lc.tlas_nodes, lc.instance_visits, lc.blas_nodes, lc.triangles};

@@ -45,6 +45,10 @@ static_assert(kScanLeafMin <= 255u, "leaves of kBigLeaf triangles or more must g
 
 struct LaneCounts {
   uint32_t tlas_nodes = 0, instance_visits = 0, blas_nodes = 0, triangles = 0;
+  // of `triangles`: those tested in whole-wave scans, by where the scan read them
+  // (the LDS leaf cache, or lane-interleaved scan blocks in memory); the rest were
+  // fetched one 48-byte record per lane step
+  uint32_t tri_wave_lds = 0, tri_wave_mem = 0;
 };
 
 struct BestHit {
@@ -377,11 +381,17 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
               // a scan tests every triangle (ANY: up to the first accepted one) except the excluded one
               const uint32_t tested = ANY ? (wp - ostart + 1u) : ocount;
               const bool skipped = oskip >= ostart && oskip < ostart + tested;
-              lc.triangles += tested - (skipped ? 1u : 0u);
+              const uint32_t n_tested = tested - (skipped ? 1u : 0u);
+              lc.triangles += n_tested;
+              if (ocached != 0u) lc.tri_wave_lds += n_tested;
+              else lc.tri_wave_mem += n_tested;
             }
           } else if (COUNT && mine) {
             const bool skipped = oskip >= ostart && oskip < ostart + ocount;
-            lc.triangles += ocount - (skipped ? 1u : 0u);
+            const uint32_t n_tested = ocount - (skipped ? 1u : 0u);
+            lc.triangles += n_tested;
+            if (ocached != 0u) lc.tri_wave_lds += n_tested;
+            else lc.tri_wave_mem += n_tested;
           }
           if (mine) {
             leaf_count = 0u;

@@ -30,6 +30,8 @@ enum QueueId {
 enum StatId {
   S_EXTEND_RAYS = 0, S_CONNECT_RAYS, S_SHADE_EVENTS, S_SPAWNED, S_FINISHED,
   S_EXT_TLAS, S_EXT_INST, S_EXT_BLAS, S_EXT_TRI, S_CON_TLAS, S_CON_INST, S_CON_BLAS, S_CON_TRI,
+  S_EXT_TRI_LDS, S_EXT_TRI_MEM, S_CON_TRI_LDS, S_CON_TRI_MEM,  // whole-wave scans, by where they read their triangles
+  S_OVERFLOW,  // samples whose add would have wrapped a 32-bit radiance sum (the sum saturates instead)
   S_PHASE0,  // eight words written only by diagnostic builds (-DMIRT_PHASE_TIMING)
   S_COUNT = S_PHASE0 + 8
 };
@@ -125,5 +127,11 @@ void launch_math_selftest(hipStream_t stream, const float *a, const float *b, co
 int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
                       uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
                       float *device_ms, void **workspace, size_t *workspace_bytes, std::string &err);
+
+// Lane-steps per second of per-lane dependent 32-byte gathers from a table of
+// `table_bytes` (diag.hip): the best of `repeats` launches of `steps` steps per
+// lane, one 1024-thread block per CU.  Allocates and frees the table.
+int gather_ceiling(hipStream_t stream, int num_cus, size_t table_bytes, uint32_t steps, uint32_t repeats,
+                   double *lane_steps_per_s, std::string &err);
 
 }  // namespace mirt

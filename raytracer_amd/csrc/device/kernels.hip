@@ -37,12 +37,26 @@ __device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
   return (uint32_t)x;
 }
 
+// One channel of a sum.  The reference's InterlockedAdd wraps; here a sum that
+// would pass 2^32 - 1 ends on 2^32 - 1 whatever the order of the adds: an add that
+// wraps is followed by an atomic max with 2^32 - 1, and so is every positive
+// add that comes after it.  Returns true when that happened.
+__device__ __forceinline__ bool add_saturating(uint32_t *p, uint32_t v) {
+  if (v == 0u) return false;
+  const uint32_t old = atomicAdd(p, v);
+  if (old + v >= old) return false;
+  atomicMax(p, 0xFFFFFFFFu);
+  return true;
+}
+
 // accumulateSample's sums (shaders/sample.slang:38-47) for one finished sample
 __device__ __forceinline__ void accumulate_sample(const DState &st, const DFrameParams &fp, uint32_t source, float4 rad) {
   atomicAdd(&st.count[source], 1u);
-  atomicAdd(&st.sum4[4 * (size_t)source + 0], to_fixed(rad.x, fp.p.fixed_point_scale));
-  atomicAdd(&st.sum4[4 * (size_t)source + 1], to_fixed(rad.y, fp.p.fixed_point_scale));
-  atomicAdd(&st.sum4[4 * (size_t)source + 2], to_fixed(rad.z, fp.p.fixed_point_scale));
+  uint32_t *sum = &st.sum4[4 * (size_t)source];
+  const bool o0 = add_saturating(sum + 0, to_fixed(rad.x, fp.p.fixed_point_scale));
+  const bool o1 = add_saturating(sum + 1, to_fixed(rad.y, fp.p.fixed_point_scale));
+  const bool o2 = add_saturating(sum + 2, to_fixed(rad.z, fp.p.fixed_point_scale));
+  if (o0 || o1 || o2) atomicAdd(&st.stats[S_OVERFLOW], (unsigned long long)((o0 ? 1 : 0) + (o1 ? 1 : 0) + (o2 ? 1 : 0)));
 }
 
 // camera basis (shaders/sample.slang:87-90)
@@ -225,6 +239,7 @@ __global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, D
   };
   trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
+  if (COUNT) flush_wave_scan_counts(st.stats, S_EXT_TRI_LDS, lc);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
 }
 

@@ -121,6 +121,9 @@ class Stats(C.Structure):
                 ("shade_launches", C.c_uint64), ("shade_ms", C.c_double),
                 ("sample_launches", C.c_uint64), ("sample_ms", C.c_double),
                 ("extend_counts", TraversalCounts), ("connect_counts", TraversalCounts),
+                ("extend_tri_wave_lds", C.c_uint64), ("extend_tri_wave_mem", C.c_uint64),
+                ("connect_tri_wave_lds", C.c_uint64), ("connect_tri_wave_mem", C.c_uint64),
+                ("overflowed_sums", C.c_uint64),
                 ("engine_phase", C.c_uint64 * 8)]
 
 
@@ -215,7 +218,7 @@ DEVICE_SYMBOLS = [
     "mirt_scene_upload", "mirt_scene_update_instances", "mirt_state_create", "mirt_camera_set", "mirt_reset_accum",
     "mirt_set_sample_range", "mirt_step", "mirt_render_spp", "mirt_synchronize", "mirt_read_output",
     "mirt_read_accum", "mirt_copy_accum_to_device", "mirt_load_accum_from_device",
-    "mirt_trace_closest", "mirt_trace_closest_static", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_stats",
+    "mirt_trace_closest", "mirt_trace_closest_static", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_bench_gather", "mirt_scene_bytes", "mirt_stats",
     "mirt_stats_reset", "mirt_set_counting", "mirt_set_event_timing", "mirt_dump_extension_rays",
     "mirt_math_selftest", "mirt_build_blas",
     "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_member", "mirt_group_last_error",
@@ -257,6 +260,8 @@ def device_lib():
         L.mirt_trace_closest_static.argtypes = [vp, vp, sz, vp, C.POINTER(TraversalCounts)]
         L.mirt_trace_any.argtypes = [vp, vp, vp, sz, vp, C.POINTER(TraversalCounts)]
         L.mirt_bench_trace_closest.argtypes = [vp, vp, sz, u32, C.POINTER(C.c_double)]
+        L.mirt_bench_gather.argtypes = [vp, sz, u32, u32, C.POINTER(C.c_double)]
+        L.mirt_scene_bytes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.mirt_stats.argtypes = [vp, C.POINTER(Stats)]
         L.mirt_stats_reset.argtypes = [vp]
         L.mirt_set_counting.argtypes = [vp, i32]

@@ -176,6 +176,17 @@ class Pathtracer:
                     "mirt_bench_trace_closest")
         return ms.value
 
+    def bench_gather(self, table_bytes=0, steps=512, repeats=3):
+        """Lane-steps/s of dependent 32-byte gathers from a table (0 = the scene's size)."""
+        r = C.c_double()
+        self._check(self._L.mirt_bench_gather(self._h, table_bytes, steps, repeats, C.byref(r)), "mirt_bench_gather")
+        return r.value
+
+    def scene_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._L.mirt_scene_bytes(self._h, C.byref(a), C.byref(b)), "mirt_scene_bytes")
+        return a.value, b.value
+
     def dump_extension_rays(self, capacity):
         out = np.zeros(capacity, ffi.Ray)
         n = C.c_size_t()

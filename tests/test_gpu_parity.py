@@ -295,6 +295,37 @@ def test_bounce_rays_dumped_from_the_device_match_the_oracle(pt, config_scenes):
     assert np.array_equal(key(got), key(want))  # queue order is free, the set is not
 
 
+@pytest.mark.parametrize("cfg,W,H,slots,frames", [(1, 64, 64, 64 * 64, 9), (2, 64, 36, 1000, 23)])
+def test_step_frames_accumulate_what_the_wavefront_simulation_does(pt, config_scenes, cfg, W, H, slots, frames):
+    # mirt_step is the call a per-frame host makes (pathtracer_phase_execute,
+    # src/pathtracer_manager.rs:74-124): F frames of it — the three-kernel frame, samples
+    # regenerating without a budget — against F frames of the oracle's queue simulation:
+    # sums, counts and the ray / shade / sample statistics, in both shading modes, with as
+    # many slots as pixels (the reference's shape) and with far fewer
+    arrays, info = config_scenes(cfg)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    for mode in (0, 1):
+        prm = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=mode, nee=mode)
+        oprm = po.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=mode, nee=mode)
+        pt.create_state(W, H, slots, src, prm)
+        pt.set_camera(cam)
+        pt.stats_reset()
+        pt.step(frames - 3)
+        pt.step(3)  # frames of separate calls continue the same wavefront
+        pt.synchronize()
+        s4, cnt = pt.read_accum()
+        w4, wcnt, wst = sc.step_wavefront(cam, src, W, H, oprm, 0, frames, slots)
+        assert wst.finished_samples > slots  # slots were recycled
+        assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4)
+        st = pt.stats()
+        assert (st.extend_rays, st.connect_rays, st.shade_events, st.finished_samples) == (
+            wst.extend_rays, wst.connect_rays, wst.shade_events, wst.finished_samples)
+        assert st.frames == frames and st.overflowed_sums == 0
+
+
 def test_errors_are_reported_not_thrown(pt, config_scenes):
     arrays, _ = config_scenes(1)
     bad = {k: v.copy() for k, v in arrays.items()}
