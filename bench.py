@@ -42,6 +42,9 @@ SCENES = {1: "suzanne under a rect light",
           4: "10x10x10 grid of dragon/teapot/suzanne/cube instances",
           5: "Cornell box with ceiling light + dielectric dragon, light sampling"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# what stands for dragon.obj (ConfigInfo.procedural_dragon)
+GEOMETRY = {0: "dragon asset", 1: "procedural dragon-class knot, 871040 triangles (largest BVH leaf 2888)",
+            2: "suzanne asset with every triangle split into four five times, jittered: 991232 triangles (largest BVH leaf 602)"}
 
 
 def parse():
@@ -53,10 +56,14 @@ def parse():
     ap.add_argument("--paths-per-pixel", type=int, default=32,
                     help="paths in flight (slots of the wavefront state) per pixel")
     ap.add_argument("--config", type=int, default=3)
+    ap.add_argument("--geometry", choices=["knot", "suzanne"], default="knot",
+                    help="stand-in for the absent dragon asset: the procedural knot (871 040 triangles) or "
+                         "suzanne with every triangle split into four five times (991 232 triangles)")
     ap.add_argument("--mode", choices=["render", "step"], default="render",
                     help="render: mirt_render_spp passes (the headline); step: mirt_step, one call per frame, at the "
                          "reference's operating point (512x512, one path slot per pixel, src/pathtracer.rs:34-38)")
     ap.add_argument("--frames-per-step", type=int, default=64, help="step mode: frames per bench step")
+    ap.add_argument("--step-paths-per-pixel", type=int, default=1, help="step mode: path slots per pixel")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,16 +115,21 @@ def device_sources_sha():
 def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
     """What bounds the extend kernel, from this run's own measurements.
 
-    The walk is a per-lane chain of dependent small fetches; the scene sits in L2 + Infinity
-    Cache, so the binding resource is the rate at which the memory pipeline serves such
-    gathers, not HBM.  achieved = bytes the lanes actually request per launch (32 B per node
-    visit, 48 B per triangle fetched by a lane, 36 B per triangle of a whole-wave scan read
-    from memory, 68 B per instance visit, 48 B per ray in and out) / the kernel's mean launch
-    time (HIP events on its stream); peak = 32 B x the lane-steps/s of dependent 32-byte
-    gathers from a table of this scene's size, measured now, untimed, with the same block
-    shape.  Triangle tests served from the LDS leaf cache move no memory and are listed apart.
-    hbm_frac = memory-side bytes per launch from the PMC counters (profiles/traffic.json, used
-    only when it was taken on these sources) / launch time / 8 TB/s."""
+    The walk is a per-lane chain of dependent small fetches and the scene sits in L2 +
+    Infinity Cache, so the binding resource is the rate at which the memory pipeline serves
+    per-lane gathers, not HBM streaming.
+      achieved  bytes the lanes actually request per launch (32 B per node visit, 48 B per
+                triangle fetched by a lane, 36 B per triangle of a whole-wave scan read from
+                memory, 68 B per instance visit, 48 B per ray in and out) / the kernel's mean
+                launch time (HIP events on its stream)
+      peak      32 B x the lane-steps/s of dependent 32-byte gathers from a table that fits an
+                XCD's L2 (mirt_bench_gather, measured now, untimed, same block shape): the most
+                the L1 / texture-address path delivers to per-lane gathers, whatever the hit rates
+    Triangle tests served from the LDS leaf cache move no memory and are listed apart.  Behind the
+    L1 the second stage is the L2-miss path: fabric_frac = memory-side read requests per second
+    (FETCH_SIZE / 64 B from profiles/traffic.json, used only when it was taken on these very
+    sources) / the line rate of the same gather from a 192 MiB table (Infinity-Cache resident,
+    2 % L2 hits), also measured now.  hbm_frac = memory-side bytes / launch time / 8 TB/s."""
     launches = max(int(st.extend_launches), 1)
     ext_s = st.extend_ms * 1e-3 / launches
     c = cst.extend_counts
@@ -126,12 +138,13 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
     tri_lane = int(c.triangles) - tri_lds - tri_scan
     requested = 32 * nodes + 48 * tri_lane + 36 * tri_scan + 68 * c.instance_visits + 48 * c.rays
     scene_bytes, cache_bytes = pt.scene_bytes()
-    gather_rate = pt.bench_gather(0, 512, 3)          # lane-steps/s, table = this scene's nodes + triangles
-    gather_rate_l2 = pt.bench_gather(2 << 20, 512, 3)  # the same from a table that fits one XCD's L2
+    gather_l2 = pt.bench_gather(2 << 20, 512, 3)     # lane-steps/s, table inside one XCD's L2
+    gather_scene = pt.bench_gather(0, 512, 3)        # table = this scene's nodes + triangles, uniformly random
+    gather_mall = pt.bench_gather(192 << 20, 512, 3)  # table beyond L2, inside the Infinity Cache
     achieved = requested / launches / ext_s / 1e9 if ext_s > 0 else 0.0
-    peak = gather_rate * 32 / 1e9
+    peak = gather_l2 * 32 / 1e9
     alg_bytes = c.algorithmic_bytes(112)
-    traffic = traffic_src = None
+    traffic = traffic_src = fabric_frac = None
     try:
         tj = json.load(open(args.traffic_json))
         if (tj.get("workload") == workload and tj.get("paths_in_flight") == n_paths
@@ -139,6 +152,8 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
             traffic = tj.get("memory_side_bytes_per_extend_launch")
             traffic_src = {k: tj.get(k) for k in ("measured_at_head", "fetch_size_bytes", "write_size_bytes",
                                                   "fetch_calibration")}
+            if gather_mall > 0 and ext_s > 0:
+                fabric_frac = tj["fetch_size_bytes"] / 64.0 / ext_s / gather_mall
     except Exception:
         traffic = None
     per_ray = {"tlas_nodes": c.tlas_nodes / max(c.rays, 1), "instance_visits": c.instance_visits / max(c.rays, 1),
@@ -148,12 +163,13 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
                "triangles_in_whole_wave_scans_from_memory": tri_scan / max(c.rays, 1)}
     return {
         "bound": "hbm", "kernel": "k_extend", "unit": "GB/s",
-        "binding_resource": "dependent per-lane gathers through L1 miss path / L2 / Infinity Cache (scene resident on die)",
+        "binding_resource": "per-lane dependent gathers: L1 / texture-address path first, L2-miss path second "
+                            "(the scene is resident in L2 + Infinity Cache; HBM itself is nearly idle)",
         "achieved": achieved, "peak": peak, "frac": achieved / peak if peak > 0 else None,
-        "peak_source": f"mirt_bench_gather in this process: {gather_rate / 1e9:.1f} G lane-steps/s x 32 B, "
-                       f"table {scene_bytes / 1e6:.1f} MB = this scene's nodes + triangles",
-        "frac_of_l2_resident_gather_rate": achieved / (gather_rate_l2 * 32 / 1e9) if gather_rate_l2 > 0 else None,
-        "gather_lane_steps_per_s": {"scene_sized_table": gather_rate, "2MiB_table": gather_rate_l2},
+        "peak_source": f"mirt_bench_gather in this process: {gather_l2 / 1e9:.1f} G lane-steps/s x 32 B from a 2 MiB table",
+        "fabric_frac": fabric_frac,
+        "gather_lane_steps_per_s": {"2MiB_table": gather_l2, "192MiB_table": gather_mall,
+                                    f"scene_sized_table_{scene_bytes / 1e6:.0f}MB_uniform": gather_scene},
         "requested_bytes_per_launch": requested / launches,
         "lds_served_triangle_tests_per_launch": tri_lds / launches,
         "lds_served_bytes_equivalent_per_launch": 48 * tri_lds / launches,
@@ -176,7 +192,8 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
     pathtracer_phase_execute submits four dispatches per frame (src/pathtracer_manager.rs:74-124),
     with T = W*H path slots (src/pathtracer.rs:34-38).  A bench step is --frames-per-step frames."""
     import torch
-    n_paths = W * H  # Pathtracer.threads = dims.0 * dims.1
+    ppp = args.step_paths_per_pixel
+    n_paths = W * H * ppp  # Pathtracer.threads = dims.0 * dims.1 in the reference (ppp = 1)
     pt.create_state(W, H, n_paths, src, params)
     pt.set_camera(cam)
     F = args.frames_per_step
@@ -203,9 +220,15 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
     pt.synchronize()
     pt.set_event_timing(False)
     ev = pt.stats()
+    # a host that waits for every frame (reads the image back each time) pays the launch latency too
+    t1 = time.perf_counter()
+    for _ in range(F):
+        pt.step(1)
+        pt.synchronize()
+    sync_ms_per_frame = (time.perf_counter() - t1) / F * 1e3
     kernel_ms_per_frame = (ev.extend_ms + ev.finish_ms + ev.shade_ms + ev.sample_ms + ev.connect_ms) / max(int(ev.frames), 1)
     wall_ms_per_frame = elapsed / max(frames, 1) * 1e3
-    geometry = "procedural dragon-class knot, 871040 triangles" if info.procedural_dragon else "dragon asset"
+    geometry = GEOMETRY[info.procedural_dragon]
     out = {
         "metric": "Mrays/s (extend+shadow), per-frame stepping", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -215,7 +238,7 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
                                f"{'per-material' if info.shade_mode else 'uber'} shading",
                    "geometry": geometry, "paths_in_flight": n_paths, "parallelism": "one GPU"},
         "frames_per_s": frames / elapsed, "wall_ms_per_frame": wall_ms_per_frame,
-        "kernel_ms_per_frame": kernel_ms_per_frame,
+        "kernel_ms_per_frame": kernel_ms_per_frame, "wall_ms_per_frame_synchronised_every_frame": sync_ms_per_frame,
         "host_and_launch_overhead_us_per_frame": (wall_ms_per_frame - kernel_ms_per_frame) * 1e3,
         "kernel_ms_per_frame_by_kernel": {"extend": ev.extend_ms / max(int(ev.frames), 1), "shade": ev.shade_ms / max(int(ev.frames), 1),
                                           "sample": ev.sample_ms / max(int(ev.frames), 1),
@@ -247,7 +270,7 @@ def main():
 
     from raytracer_amd import distributed, host, pathtracer
 
-    arrays, info = host.build_config_scene(args.config)
+    arrays, info = host.build_config_scene(args.config, standin=args.geometry)
     W = args.width or info.width
     H = args.height or info.height
     src = host.make_sample_sources(W, H, info.seed, shuffle=2)
@@ -322,11 +345,12 @@ def main():
         pt.set_counting(False)
         cst = pt.stats()
         assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
-        roofline = extend_roofline(pt, st, cst, elapsed, args, f"config{args.config} {W}x{H}", n_paths)
+        wl = f"config{args.config} {W}x{H}" + ("" if args.geometry == "knot" else f" {args.geometry}")
+        roofline = extend_roofline(pt, st, cst, elapsed, args, wl, n_paths)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
-        geometry = "procedural dragon-class knot, 871040 triangles" if info.procedural_dragon else "dragon asset"
+        geometry = GEOMETRY[info.procedural_dragon]
         out = {
             "metric": "Mrays/s (extend+shadow), dragon 1080p",
             "value": rays / elapsed / 1e6,

@@ -37,6 +37,19 @@ int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positio
 int mirth_load_mesh_model_file(mirth_scene *s, const char *path);
 /* Procedural dragon-class mesh: 2*n_u*n_v triangles. */
 int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed);
+/* <asset_dir>/<name>.obj (or .mirtmesh) with every triangle split into four
+ * `levels` times and the new vertices jittered by a seeded +-4 % of their edge:
+ * a scan-like mesh with the asset's topology (suzanne x 4^5 = 991 232
+ * triangles).  File normals are dropped (computed normals, src/mesh.rs:357-413). */
+int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels,
+                               uint32_t seed);
+/* The sin / cos the procedural meshes are built with: IEEE +, -, * on doubles
+ * only, so their vertices do not depend on the host's libm. */
+void mirth_det_sincos(double x, double *s_out, double *c_out);
+/* What mirth_build_config uses when the dragon asset is absent: kind 0 = the
+ * knot (default), 1 = suzanne subdivided `levels` times.  Call before
+ * mirth_build_config. */
+int mirth_set_dragon_standin(mirth_scene *s, int kind, uint32_t levels);
 
 /* The BLAS of every mesh loaded AFTER this call is built by `fn` instead of the
  * host builder (NULL restores the host builder).  `fn` has the signature of
@@ -75,7 +88,7 @@ int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3],
  * per pixel, bounce limit, shade mode and whether the dragon was procedural. */
 typedef struct MirthConfigInfo {
   uint32_t width, height, spp, max_bounces, shade_mode, nee;
-  uint32_t procedural_dragon;
+  uint32_t procedural_dragon; /* 0 = asset, 1 = procedural knot, 2 = subdivided suzanne */
   uint32_t seed;
 } MirthConfigInfo;
 int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32_t dragon_n_u,

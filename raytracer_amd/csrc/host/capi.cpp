@@ -14,6 +14,10 @@ struct mirth_scene {
   Scene scene;
   std::string error;
   bool bound = false;
+  // what stands in for the absent dragon asset: 0 = the procedural knot,
+  // 1 = suzanne with every triangle split into four `standin_levels` times
+  int standin_kind = 0;
+  uint32_t standin_levels = 5;
 };
 
 namespace {
@@ -173,6 +177,42 @@ int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t se
   return added(s, s->scene.add_mesh(key, Mesh::from_model(make_knot_model(n_u, n_v, seed))));
 }
 
+int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels, uint32_t seed) {
+  if (!s || !asset_dir || !name || levels > 8) return -1;
+  const std::string dir = asset_dir;
+  std::string key = std::string("SUBDIV:") + dir + "/" + name + ":" + std::to_string(levels) + ":" + std::to_string(seed);
+  auto it = s->scene.by_desc.find(key);
+  if (it != s->scene.by_desc.end()) return (int)it->second;
+  ObjModel base;
+  const std::string obj = dir + "/" + name + ".obj", mm = dir + "/" + name + ".mirtmesh";
+  if (file_exists(obj)) {
+    if (!load_obj_first_model(obj, base, s->error)) return -1;
+  } else if (file_exists(mm)) {
+    if (!read_model_file(mm, base, s->error)) return -1;
+  } else {
+    s->error = std::string("asset ") + name + " not found in " + dir;
+    return -1;
+  }
+  if (!validate_model(base, s->error)) return -1;
+  if ((base.indices.size() / 3) << (2 * levels) > (size_t)1 << 24) {
+    s->error = "subdivided mesh would exceed 2^24 triangles";
+    return -1;
+  }
+  return added(s, s->scene.add_mesh(key, Mesh::from_model(subdivide_model(base, levels, seed))));
+}
+
+void mirth_det_sincos(double x, double *s_out, double *c_out) {
+  if (s_out) *s_out = host_det_sin(x);
+  if (c_out) *c_out = host_det_cos(x);
+}
+
+int mirth_set_dragon_standin(mirth_scene *s, int kind, uint32_t levels) {
+  if (!s || kind < 0 || kind > 1 || levels > 8) return -1;
+  s->standin_kind = kind;
+  s->standin_levels = levels;
+  return 0;
+}
+
 int mirth_add_material(mirth_scene *s, const MirtMaterial *m) {
   if (!s || !m) return -1;
   return (int)s->scene.add_material(*m);
@@ -246,6 +286,10 @@ int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32
     std::string obj = dir + "/dragon.obj", mm = dir + "/dragon.mirtmesh";
     if (file_exists(obj)) return mirth_load_mesh_obj(s, obj.c_str());
     if (file_exists(mm)) return mirth_load_mesh_model_file(s, mm.c_str());
+    if (s->standin_kind == 1) {
+      info->procedural_dragon = 2;
+      return mirth_load_mesh_subdivided(s, dir.c_str(), "suzanne", s->standin_levels, 1);
+    }
     info->procedural_dragon = 1;
     return mirth_load_mesh_knot(s, dragon_n_u, dragon_n_v, 1);
   };

@@ -110,6 +110,12 @@ MirtBVHNode to_gpu(const BVHNode &n);  // src/bvh.rs:212-224
 // (p,q) torus-knot tube with seeded multi-octave displacement, written as an
 // ObjModel without normals (so Mesh::from_model computes them).
 ObjModel make_knot_model(uint32_t n_u, uint32_t n_v, uint32_t seed);
+// A loaded model with every triangle split into four `levels` times and the
+// new vertices jittered by a seeded fraction of their edge (no file normals).
+ObjModel subdivide_model(const ObjModel &in, uint32_t levels, uint32_t seed);
+// sin / cos from IEEE +, -, * only (the procedural meshes use nothing else)
+double host_det_sin(double x);
+double host_det_cos(double x);
 
 // ECS entity (Transform, MeshId, MaterialId) of src/binder.rs:52.
 struct Entity {

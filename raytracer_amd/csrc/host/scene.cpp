@@ -7,6 +7,8 @@
 
 #include <string>
 
+#include <unordered_map>
+
 #include "host.hpp"
 
 namespace mirth {
@@ -262,10 +264,63 @@ void spawn_cornell(Scene &s, Vec3 dims, Vec3 pos, bool with_ceiling_light) {
 
 // ------------------------------------------------------- procedural "dragon"
 
+namespace {
+
+// sin and cos from +, -, * and comparisons on IEEE doubles only (this library is
+// built without contraction), so that the procedural meshes come out with the
+// same bits on every host whatever its libm: Cody-Waite reduction by pi/2 in
+// two pieces (arguments here stay below a few thousand), then the Taylor
+// polynomials on [-pi/4, pi/4], whose first neglected terms are below 1e-19.
+void det_sincos(double x, double &s, double &c) {
+  const double inv_pio2 = 0.63661977236758134308;
+  const double pio2_hi = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+  const double pio2_lo = 6.07710050650619224932e-11;  // pi/2 - pio2_hi
+  const double kf = x * inv_pio2;
+  const long long k = (long long)(kf < 0.0 ? kf - 0.5 : kf + 0.5);
+  const double kd = (double)k;
+  const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+  const double r2 = r * r;
+  double ps = -1.0 / 121645100408832000.0;  // r^19
+  ps = ps * r2 + 1.0 / 355687428096000.0;
+  ps = ps * r2 - 1.0 / 1307674368000.0;
+  ps = ps * r2 + 1.0 / 6227020800.0;
+  ps = ps * r2 - 1.0 / 39916800.0;
+  ps = ps * r2 + 1.0 / 362880.0;
+  ps = ps * r2 - 1.0 / 5040.0;
+  ps = ps * r2 + 1.0 / 120.0;
+  ps = ps * r2 - 1.0 / 6.0;
+  const double sr = r + r * r2 * ps;
+  double pc = 1.0 / 2432902008176640000.0;  // r^20
+  pc = pc * r2 - 1.0 / 6402373705728000.0;
+  pc = pc * r2 + 1.0 / 20922789888000.0;
+  pc = pc * r2 - 1.0 / 87178291200.0;
+  pc = pc * r2 + 1.0 / 479001600.0;
+  pc = pc * r2 - 1.0 / 3628800.0;
+  pc = pc * r2 + 1.0 / 40320.0;
+  pc = pc * r2 - 1.0 / 720.0;
+  pc = pc * r2 + 1.0 / 24.0;
+  pc = pc * r2 - 0.5;
+  const double cr = 1.0 + r2 * pc;
+  switch ((int)(k & 3)) {
+    case 0: s = sr; c = cr; break;
+    case 1: s = cr; c = -sr; break;
+    case 2: s = -sr; c = -cr; break;
+    default: s = -cr; c = sr; break;
+  }
+}
+double det_sin(double x) { double s, c; det_sincos(x, s, c); return s; }
+double det_cos(double x) { double s, c; det_sincos(x, s, c); return c; }
+
+}  // namespace
+
+double host_det_sin(double x) { return det_sin(x); }
+double host_det_cos(double x) { return det_cos(x); }
+
 ObjModel make_knot_model(uint32_t n_u, uint32_t n_v, uint32_t seed) {
   // A (2,3) torus knot swept by a tube whose radius is displaced by a few
   // octaves of seeded sinusoids: a closed, bumpy, self-occluding surface with
-  // 2*n_u*n_v triangles.  Deterministic for a given libm.
+  // 2*n_u*n_v triangles.  Only IEEE +, -, *, / and sqrt are used (det_sincos
+  // above), so the mesh has the same bits on every host.
   ObjModel m;
   SplitMix64 rng(0xD8A60000ull + seed);
   const int kOct = 5;
@@ -282,10 +337,10 @@ ObjModel make_knot_model(uint32_t n_u, uint32_t n_v, uint32_t seed) {
     double u = two_pi * (double)i / (double)n_u;
     // knot centre line and its frame
     auto curve = [](double t, double c[3]) {
-      double r = 2.0 + cos(3.0 * t);
-      c[0] = r * cos(2.0 * t);
-      c[1] = r * sin(2.0 * t);
-      c[2] = -sin(3.0 * t) * 1.5;
+      double r = 2.0 + det_cos(3.0 * t);
+      c[0] = r * det_cos(2.0 * t);
+      c[1] = r * det_sin(2.0 * t);
+      c[2] = -det_sin(3.0 * t) * 1.5;
     };
     double c0[3], c1[3];
     curve(u, c0);
@@ -303,8 +358,8 @@ ObjModel make_knot_model(uint32_t n_u, uint32_t n_v, uint32_t seed) {
     for (uint32_t j = 0; j < n_v; ++j) {
       double v = two_pi * (double)j / (double)n_v;
       double rad = 0.55;
-      for (int o = 0; o < kOct; ++o) rad += 0.55 * am[o] * sin(fu[o] * u + fv[o] * v + ph[o]);
-      double cx = cos(v) * rad, sx = sin(v) * rad;
+      for (int o = 0; o < kOct; ++o) rad += 0.55 * am[o] * det_sin(fu[o] * u + fv[o] * v + ph[o]);
+      double cx = det_cos(v) * rad, sx = det_sin(v) * rad;
       m.positions.push_back((float)(c0[0] + cx * nx + sx * bx));
       m.positions.push_back((float)(c0[1] + cx * ny + sx * by));
       m.positions.push_back((float)(c0[2] + cx * nz + sx * bz));
@@ -319,6 +374,56 @@ ObjModel make_knot_model(uint32_t n_u, uint32_t n_v, uint32_t seed) {
       uint32_t t[6] = {a, b, c, a, c, dd};
       m.indices.insert(m.indices.end(), t, t + 6);
     }
+  }
+  return m;
+}
+
+// --------------------------------------------- subdivided asset ("scan-like")
+
+ObjModel subdivide_model(const ObjModel &in, uint32_t levels, uint32_t seed) {
+  // Every level splits each triangle into four at its edge midpoints; a midpoint
+  // is then moved by a seeded pseudo-random offset of at most +-4 % of its edge's
+  // length per axis (scanner-like irregularity: no two centroids or box faces
+  // coincide exactly).  File normals are dropped, so the mesh takes the
+  // computed-normal path of Mesh::from_model.  Integer hashing and IEEE +, -, *
+  // only: the same bits on every host.
+  ObjModel m;
+  m.positions = in.positions;
+  m.indices = in.indices;
+  auto hash32 = [](uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+  };
+  for (uint32_t level = 0; level < levels; ++level) {
+    std::unordered_map<uint64_t, uint32_t> mid;
+    mid.reserve(m.indices.size());
+    std::vector<uint32_t> out;
+    out.reserve(m.indices.size() * 4);
+    auto midpoint = [&](uint32_t a, uint32_t b) {
+      const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+      auto it = mid.find(key);
+      if (it != mid.end()) return it->second;
+      const uint32_t id = (uint32_t)(m.positions.size() / 3);
+      const float *pa = &m.positions[(size_t)a * 3], *pb = &m.positions[(size_t)b * 3];
+      const float ex = pb[0] - pa[0], ey = pb[1] - pa[1], ez = pb[2] - pa[2];
+      const float len = sqrtf(ex * ex + ey * ey + ez * ez);
+      float p[3];
+      for (int k = 0; k < 3; ++k) {
+        const uint32_t h = hash32(hash32(id * 3u + (uint32_t)k) ^ (seed * 0x9E3779B9u + level));
+        const float j = ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.08f;  // [-0.04, 0.04)
+        p[k] = (pa[k] + pb[k]) * 0.5f + j * len;
+      }
+      m.positions.insert(m.positions.end(), p, p + 3);
+      mid.emplace(key, id);
+      return id;
+    };
+    for (size_t t = 0; t + 2 < m.indices.size(); t += 3) {
+      const uint32_t a = m.indices[t], b = m.indices[t + 1], c = m.indices[t + 2];
+      const uint32_t ab = midpoint(a, b), bc = midpoint(b, c), ca = midpoint(c, a);
+      const uint32_t tri[12] = {a, ab, ca, ab, b, bc, ca, bc, c, ab, bc, ca};
+      out.insert(out.end(), tri, tri + 12);
+    }
+    m.indices.swap(out);
   }
   return m;
 }

@@ -193,6 +193,10 @@ def host_lib():
         L.mirth_load_mesh_model.argtypes = [vp, C.c_char_p, vp, u32, vp, u32, vp, u32]
         L.mirth_load_mesh_model_file.argtypes = [vp, C.c_char_p]
         L.mirth_load_mesh_knot.argtypes = [vp, u32, u32, u32]
+        L.mirth_load_mesh_subdivided.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32]
+        L.mirth_set_dragon_standin.argtypes = [vp, i32, u32]
+        L.mirth_det_sincos.restype = None
+        L.mirth_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mirth_add_material.argtypes = [vp, vp]
         L.mirth_default_material.argtypes = [vp]
         L.mirth_default_camera.argtypes = [vp]

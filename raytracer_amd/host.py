@@ -140,6 +140,16 @@ class Scene:
     def load_knot(self, n_u, n_v, seed=1):
         return self._check(self._L.mirth_load_mesh_knot(self._h, n_u, n_v, seed), "load_knot")
 
+    def load_subdivided(self, name, levels, seed=1, asset_dir=None):
+        """An asset with every triangle split into four `levels` times (jittered midpoints)."""
+        return self._check(self._L.mirth_load_mesh_subdivided(self._h, (asset_dir or default_asset_dir()).encode(),
+                                                              name.encode(), levels, seed), "load_subdivided")
+
+    def set_dragon_standin(self, kind, levels=5):
+        """What replaces the absent dragon asset in build_config: 'knot' or 'suzanne' (subdivided `levels` times)."""
+        self._check(self._L.mirth_set_dragon_standin(self._h, {"knot": 0, "suzanne": 1}[kind], levels),
+                    "set_dragon_standin")
+
     def mesh(self, mesh_id):
         """(positions[n,4], normals[n,4], faces[m,4], nodes[k]) of a built mesh."""
         nv, nf, nn = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -184,9 +194,10 @@ class Scene:
         return ffi.arrays_from_desc(d)
 
 
-def build_config_scene(config, asset_dir=None, dragon_n_u=0, dragon_n_v=0):
+def build_config_scene(config, asset_dir=None, dragon_n_u=0, dragon_n_v=0, standin="knot", standin_levels=5):
     """(arrays, info) for benchmark configuration 1..5."""
     s = Scene()
+    s.set_dragon_standin(standin, standin_levels)
     info = s.build_config(config, asset_dir, dragon_n_u, dragon_n_v)
     arrays = s.bind()
     s.close()

@@ -1131,3 +1131,33 @@ def test_oracle_rejects_inconsistent_scene_buffers(config_scenes):
     bad["indices"]["v"][0, 0] = 10 ** 6
     with pytest.raises(ValueError):
         po.Scene(bad)
+
+
+def test_procedural_meshes_use_their_own_trigonometry_and_have_pinned_bits():
+    # the stand-in geometry must not depend on the host's libm: sin / cos come from IEEE +, -, *
+    # on doubles (checked here against numpy to an ulp), and the meshes built from them hash
+    # to the values computed when the generator was written
+    import ctypes as C
+    import hashlib
+    L = ffi.host_lib()
+    s_out, c_out = C.c_double(), C.c_double()
+    worst = 0.0
+    for x in np.concatenate([np.linspace(-50.0, 900.0, 4001), [0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, 1e-300]]):
+        L.mirth_det_sincos(float(x), C.byref(s_out), C.byref(c_out))
+        worst = max(worst, abs(s_out.value - np.sin(x)), abs(c_out.value - np.cos(x)))
+    assert worst < 2.3e-16
+    s = host.Scene()
+    pos, _, faces, nodes = s.mesh(s.load_knot(96, 24, 7))
+    assert (len(pos), len(faces), len(nodes)) == (2304, 4608, 3287)
+    assert hashlib.sha256(pos.tobytes()).hexdigest()[:32] == "6c9e645ed123bd2e551fd73e77e7e200"
+    # suzanne with every triangle split in four, twice: 968 * 16 triangles, V + E new vertices per level
+    pos, nrm, faces, nodes = s.mesh(s.load_subdivided("suzanne", 2))
+    assert (len(pos), len(faces), len(nodes)) == (7824, 15488, 11255)
+    assert hashlib.sha256(pos.tobytes()).hexdigest()[:32] == "d2f94e268460238522170f72d730122b"
+    assert np.all(np.isfinite(nrm)) and np.all(np.abs(pos[:, :3]) <= 1.0 + 1e-6)  # normalised like any loaded mesh
+    s.close()
+    # configuration 3 with the subdivided asset standing in for the dragon
+    arrays, info = host.build_config_scene(3, standin="suzanne", standin_levels=2)
+    assert info.procedural_dragon == 2 and len(arrays["indices"]) == 12 + 15488 + 2
+    arrays, info = host.build_config_scene(3, dragon_n_u=64, dragon_n_v=16)
+    assert info.procedural_dragon == 1 and len(arrays["indices"]) == 12 + 2 * 64 * 16 + 2
