@@ -181,7 +181,17 @@ typedef struct MirtSceneDesc {
 
 /* --------------------------------------------------------------- parameters */
 enum { MIRT_SHADE_UBER = 0, MIRT_SHADE_CLASSIC = 1 };
-enum { MIRT_RNG_PER_SAMPLE = 0 };
+/* MIRT_RNG_PER_SAMPLE: every sample's stream is keyed by (seed, source,
+ * sample number): results do not depend on path slot, queue order or GPU count.
+ * MIRT_RNG_PER_SLOT: the reference's scheme — one persistent stream per path
+ * slot, seeded by the host (src/pathtracer_state.rs:98-110, set with
+ * mirt_state_set_rng) and advanced by whatever path runs in the slot
+ * (shaders/random.slang:32-36).  Which sample a slot takes next then changes
+ * the picture; the reference leaves that to the arrival order of its atomics,
+ * here the slots that ended in a frame take the next sample numbers in
+ * ascending slot order, one of the runs the reference can make and the same
+ * on every run.  Single GPU, sample stage on one CU: for comparison runs. */
+enum { MIRT_RNG_PER_SAMPLE = 0, MIRT_RNG_PER_SLOT = 1 };
 
 /* Every literal of the reference kernels that a configuration changes. */
 typedef struct MirtParams {
@@ -193,6 +203,9 @@ typedef struct MirtParams {
   uint32_t rng_mode;      /* MIRT_RNG_* */
   uint32_t seed;          /* RNG stream seed (keyed with source and sample number) */
   uint32_t nee;           /* classic mode: 1 = trace connect (shadow) rays */
+  uint32_t adaptive;      /* 1 = keep per-source second moments (the reference's unused sample_std,
+                             shaders/pathtracer.slang:31) so that mirt_adapt_update can flag sources */
+  uint32_t reserved;      /* 0 */
 } MirtParams;
 
 /* --------------------------------------------------------------- ray-set API */
@@ -288,6 +301,11 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height,
                       uint32_t threads, const MirtSampleSource *sources,
                       uint32_t n_sources, const MirtParams *params);
 
+/* MIRT_RNG_PER_SLOT only: the host's random-state vector, one uint4 per path
+ * slot (PathtracerState::new, src/pathtracer_state.rs:98-110: every word in
+ * [1000, 2^32)).  n_slots must equal `threads`; required before rendering. */
+int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots);
+
 /* Replaces Camera::update (src/camera.rs:193-199).  `changed != 0` resets the
  * accumulators like sampleCleanup (shaders/sample.slang:123-145). */
 int mirt_camera_set(mirt_ctx *ctx, const MirtCamera *camera);
@@ -321,6 +339,29 @@ int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels);
  * indexed by sample source. */
 int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count,
                     size_t n_sources);
+
+/* ------------------------------------------------------ adaptive sampling
+ * The reference declares the hooks and never uses them: SampleFlag::Converged
+ * (shaders/common.slang:141-144), SampleSource.flags, the sample_std buffer
+ * (shaders/pathtracer.slang:31), and a spawn that skips a flagged source
+ * (shaders/archive/logic.slang:113-116).  With MirtParams.adaptive = 1 every
+ * finished sample also adds y = r + g + b (fixed point, clamped to 24 bits) and
+ * y^2 to two 64-bit integers per source.  mirt_adapt_update sets flag bit 0 of
+ * every source with at least min_samples samples whose mean's standard error
+ * is at most rel_threshold x the mean, and from then on render calls hand
+ * samples to the unflagged sources only: mirt_render_spp(spp) renders spp
+ * further samples for each of THOSE.  Sources flagged in the array given to
+ * mirt_state_create are skipped from the start.  Flags are cleared by
+ * mirt_reset_accum / a changed camera, as sampleCleanup clears them
+ * (shaders/sample.slang:137).  Synchronises.  n_active (may be NULL) receives
+ * the number of sources still sampled. */
+int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active);
+int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources);
+/* moments[2*i] = sum of y, moments[2*i+1] = sum of y^2 of source i.  Integers: a
+ * multi-GPU host adds them across ranks, writes the totals back on every rank
+ * and calls mirt_adapt_update there, which then flags the same sources everywhere. */
+int mirt_read_moments(mirt_ctx *ctx, uint64_t *moments, size_t n_sources);
+int mirt_write_moments(mirt_ctx *ctx, const uint64_t *moments, size_t n_sources);
 
 /* Copy the accumulators into caller-owned DEVICE buffers (for an RCCL
  * reduction driven by the caller) and load reduced values back. */

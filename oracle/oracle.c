@@ -516,7 +516,8 @@ static void spawn_sample(path *p, const MirtCamera *cam, const MirtSampleSource 
   p->source = source;
   p->sample_no = sample_no;
   p->throughput = V3(1.0f, 1.0f, 1.0f);
-  oracle_rng_init(prm->seed, source, sample_no, p->rng);
+  /* per-slot streams (shaders/random.slang:32-36) are never re-seeded */
+  if (prm->rng_mode != MIRT_RNG_PER_SLOT) oracle_rng_init(prm->seed, source, sample_no, p->rng);
   p->ray_pos = ld3(cam->position);
   p->last_inst = NO_PRIM; /* int.maxValue */
   p->last_prim = NO_PRIM;
@@ -674,10 +675,20 @@ static int sat_add(uint32_t *p, uint32_t v) {
   } while (!__atomic_compare_exchange_n(p, &old, nv, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
   return sat;
 }
+/* `moments` (may be NULL): per source the sum and the sum of squares of
+ * y = min(r + g + b in fixed point, 2^24 - 1) — the integer form of the
+ * reference's declared-but-unused sample_std (shaders/pathtracer.slang:31). */
+static uint64_t *g_moments = NULL; /* set for the duration of a render call that keeps moments */
 static uint32_t accumulate_sample(const path *p, const MirtParams *prm, uint32_t *sum4, uint32_t *count) {
   const uint32_t fx = to_fixed(p->rad.x, prm->fixed_point_scale);
   const uint32_t fy = to_fixed(p->rad.y, prm->fixed_point_scale);
   const uint32_t fz = to_fixed(p->rad.z, prm->fixed_point_scale);
+  if (g_moments) {
+    uint64_t y = (uint64_t)fx + (uint64_t)fy + (uint64_t)fz;
+    if (y > 0xFFFFFFull) y = 0xFFFFFFull;
+    __atomic_fetch_add(&g_moments[2 * (size_t)p->source], y, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_moments[2 * (size_t)p->source + 1], y * y, __ATOMIC_RELAXED);
+  }
 #pragma omp atomic
   count[p->source] += 1;
   uint32_t sat = 0;
@@ -722,6 +733,16 @@ void oracle_render(const oracle_scene *s, const MirtCamera *camera, const MirtSa
                    uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
                    uint32_t first_sample, uint32_t spp, uint32_t *sum4, uint32_t *count,
                    OracleRenderStats *stats, int threads) {
+  oracle_render_active(s, camera, sources, n_sources, width, height, params, first_sample, spp, NULL, n_sources, sum4,
+                       count, NULL, stats, threads);
+}
+
+void oracle_render_active(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                          uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                          uint32_t first_sample, uint32_t spp, const uint32_t *active, uint32_t n_active,
+                          uint32_t *sum4, uint32_t *count, uint64_t *moments, OracleRenderStats *stats, int threads) {
+  (void)n_sources;
+  g_moments = moments;
   OracleRenderStats total;
   memset(&total, 0, sizeof(total));
 #ifdef _OPENMP
@@ -729,15 +750,15 @@ void oracle_render(const oracle_scene *s, const MirtCamera *camera, const MirtSa
 #else
   (void)threads;
 #endif
-  const long n_total = (long)n_sources * (long)spp;
+  const long n_total = (long)n_active * (long)spp;
 #pragma omp parallel
   {
     OracleRenderStats st;
     memset(&st, 0, sizeof(st));
 #pragma omp for schedule(dynamic, 64)
     for (long i = 0; i < n_total; ++i) {
-      const uint32_t source = (uint32_t)(i % n_sources);
-      const uint32_t k = first_sample + (uint32_t)(i / n_sources);
+      const uint32_t source = active ? active[i % n_active] : (uint32_t)(i % n_active);
+      const uint32_t k = first_sample + (uint32_t)(i / n_active);
       path p;
       memset(&p, 0, sizeof(p));
       spawn_sample(&p, camera, &sources[source], source, k, width, height, params);
@@ -750,6 +771,34 @@ void oracle_render(const oracle_scene *s, const MirtCamera *camera, const MirtSa
     stats_add(&total, &st);
   }
   if (stats) stats_add(stats, &total);
+  g_moments = NULL;
+}
+
+/* The convergence test of adaptive sampling, in IEEE doubles operation by
+ * operation: with n samples and integer moments S1, S2 of a source,
+ * n*S2 - S1^2 <= thr^2 * S1^2 * (n - 1)  (standard error of the mean at most
+ * thr x the mean).  Sets bit 0 of flags[i]; returns the sources left unflagged. */
+uint32_t oracle_adapt_update(const uint32_t *count, const uint64_t *moments, uint32_t *flags, uint32_t n_sources,
+                             float rel_threshold, uint32_t min_samples) {
+  const double thr2 = (double)rel_threshold * (double)rel_threshold;
+  uint32_t left = 0;
+  for (uint32_t i = 0; i < n_sources; ++i) {
+    const uint32_t n = count[i];
+    if (n >= min_samples && n >= 2u) {
+      const double S1 = (double)moments[2 * (size_t)i], S2 = (double)moments[2 * (size_t)i + 1];
+      const double S1sq = S1 * S1;
+      const double lhs = (double)n * S2 - S1sq;
+      const double rhs = thr2 * S1sq * (double)(n - 1u);
+      if (lhs <= rhs) flags[i] |= 1u;
+    }
+    if ((flags[i] & 1u) == 0u) left++;
+  }
+  return left;
+}
+
+static int cmp_u32(const void *a, const void *b) {
+  const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
 }
 
 /* queuePush / queueRead (shaders/queue.slang:13-36) on one thread */
@@ -766,10 +815,15 @@ static int queue_read(lifo *q) {
 static void wavefront_run(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
                           uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
                           uint32_t first_sample, uint64_t limit, uint64_t max_frames, uint32_t slots, uint32_t *sum4,
-                          uint32_t *count, OracleRenderStats *stats, uint64_t *frames_out) {
+                          uint32_t *count, OracleRenderStats *stats, uint64_t *frames_out,
+                          const uint32_t (*slot_rng)[4]) {
   OracleRenderStats st;
   memset(&st, 0, sizeof(st));
   path *paths = (path *)calloc(slots, sizeof(path));
+  /* per-slot streams: the host's seeds (src/pathtracer_state.rs:98-110) */
+  if (slot_rng)
+    for (uint32_t i = 0; i < slots; ++i) memcpy(paths[i].rng, slot_rng[i], 16);
+  uint32_t *ended = (uint32_t *)malloc(4 * (size_t)(slots + 1));
   uint8_t *live = (uint8_t *)calloc(slots, 1);
   lifo term = {0, (uint32_t *)malloc(4 * (size_t)(slots + 1))};
   lifo ext = {0, (uint32_t *)malloc(4 * (size_t)(slots + 1))};
@@ -780,10 +834,19 @@ static void wavefront_run(const oracle_scene *s, const MirtCamera *camera, const
   for (uint32_t i = 0; i < slots; ++i) queue_push(&term, i);
   uint64_t sample_index = 0, frames = 0;
   while ((term.count > 0 || ext.count > 0 || shade.count > 0) && frames < max_frames) {
-    /* sampleMain: every thread pops at most one slot */
+    /* sampleMain: every thread pops at most one slot.  With per-slot streams
+     * the pairing of slots and sample numbers matters; the reference leaves it
+     * to the arrival order of its atomics, here the slots that ended take the
+     * next numbers in ascending slot order (one of the runs it can make). */
+    uint32_t n_ended = 0;
     for (uint32_t th = 0; th < slots; ++th) {
       int idx = queue_read(&term);
       if (idx < 0) break;
+      ended[n_ended++] = (uint32_t)idx;
+    }
+    if (slot_rng) qsort(ended, n_ended, 4, cmp_u32);
+    for (uint32_t e = 0; e < n_ended; ++e) {
+      const int idx = (int)ended[e];
       if (live[idx]) {
         st.overflowed_sums += accumulate_sample(&paths[idx], params, sum4, count);
         st.finished_samples++;
@@ -821,7 +884,7 @@ static void wavefront_run(const oracle_scene *s, const MirtCamera *camera, const
   }
   if (frames_out) *frames_out = frames;
   if (stats) stats_add(stats, &st);
-  free(paths); free(live); free(term.data); free(ext.data); free(shade.data);
+  free(paths); free(live); free(term.data); free(ext.data); free(shade.data); free(ended);
 }
 
 void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
@@ -830,7 +893,15 @@ void oracle_render_wavefront(const oracle_scene *s, const MirtCamera *camera,
                              uint32_t spp, uint32_t slots, uint32_t *sum4, uint32_t *count,
                              OracleRenderStats *stats, uint64_t *frames_out) {
   wavefront_run(s, camera, sources, n_sources, width, height, params, first_sample, (uint64_t)n_sources * spp,
-                ~(uint64_t)0, slots, sum4, count, stats, frames_out);
+                ~(uint64_t)0, slots, sum4, count, stats, frames_out, NULL);
+}
+
+void oracle_wavefront_per_slot(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                               uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                               const uint32_t (*slot_rng)[4], uint64_t sample_limit, uint64_t n_frames, uint32_t slots,
+                               uint32_t *sum4, uint32_t *count, OracleRenderStats *stats) {
+  wavefront_run(s, camera, sources, n_sources, width, height, params, 0, sample_limit, n_frames, slots, sum4, count,
+                stats, NULL, slot_rng);
 }
 
 void oracle_step_wavefront(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
@@ -838,7 +909,7 @@ void oracle_step_wavefront(const oracle_scene *s, const MirtCamera *camera, cons
                            uint32_t first_sample, uint64_t n_frames, uint32_t slots, uint32_t *sum4,
                            uint32_t *count, OracleRenderStats *stats) {
   wavefront_run(s, camera, sources, n_sources, width, height, params, first_sample, ~(uint64_t)0, n_frames, slots,
-                sum4, count, stats, NULL);
+                sum4, count, stats, NULL, NULL);
 }
 
 void oracle_bounce_rays(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,

@@ -57,6 +57,30 @@ void oracle_render(const oracle_scene *s, const MirtCamera *camera, const MirtSa
                    uint32_t first_sample, uint32_t spp, uint32_t *sum4, uint32_t *count,
                    OracleRenderStats *stats, int threads);
 
+/* oracle_render over the sources listed in active[0..n_active) only (NULL = all
+ * n_active = n_sources of them): spp samples for each, sample numbers as in
+ * oracle_render.  moments (may be NULL): per source the sum and the sum of
+ * squares of y = min(r + g + b in fixed point, 2^24 - 1), ADDED to. */
+void oracle_render_active(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                          uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                          uint32_t first_sample, uint32_t spp, const uint32_t *active, uint32_t n_active,
+                          uint32_t *sum4, uint32_t *count, uint64_t *moments, OracleRenderStats *stats, int threads);
+
+/* Adaptive sampling's convergence test; sets bit 0 of flags[i] (SampleFlag::Converged,
+ * shaders/common.slang:141-144) and returns the number of sources left unflagged. */
+uint32_t oracle_adapt_update(const uint32_t *count, const uint64_t *moments, uint32_t *flags, uint32_t n_sources,
+                             float rel_threshold, uint32_t min_samples);
+
+/* The wavefront simulation with the reference's random streams: one per path
+ * slot, seeded from slot_rng and never re-seeded (params->rng_mode must be
+ * MIRT_RNG_PER_SLOT).  Runs until sample_limit samples have been handed out and
+ * the queues are empty, or for n_frames frames.  The slots that end in a frame
+ * take the next sample numbers in ascending slot order. */
+void oracle_wavefront_per_slot(const oracle_scene *s, const MirtCamera *camera, const MirtSampleSource *sources,
+                               uint32_t n_sources, uint32_t width, uint32_t height, const MirtParams *params,
+                               const uint32_t (*slot_rng)[4], uint64_t sample_limit, uint64_t n_frames, uint32_t slots,
+                               uint32_t *sum4, uint32_t *count, OracleRenderStats *stats);
+
 /* The same samples through a sequential simulation of the wavefront: `slots`
  * path slots, LIFO queues (queue.slang), one bounce per frame in the order
  * sample -> extend -> [connect] -> shade.  Must produce identical sums. */

@@ -43,6 +43,12 @@ def lib():
                                               vp, vp, C.POINTER(RenderStats), C.POINTER(C.c_uint64)]
         L.oracle_step_wavefront.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, C.c_uint64, u32,
                                             vp, vp, C.POINTER(RenderStats)]
+        L.oracle_render_active.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp, u32, vp, vp, vp,
+                                           C.POINTER(RenderStats), C.c_int]
+        L.oracle_adapt_update.restype = u32
+        L.oracle_adapt_update.argtypes = [vp, vp, vp, u32, C.c_float, u32]
+        L.oracle_wavefront_per_slot.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), vp, C.c_uint64,
+                                                C.c_uint64, u32, vp, vp, C.POINTER(RenderStats)]
         L.oracle_bounce_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp]
         L.oracle_connect_rays.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), u32, u32, vp, vp]
         L.oracle_resolve.argtypes = [vp, vp, vp, u32, u32, u32, C.POINTER(ffi.Params), vp]
@@ -54,7 +60,8 @@ def lib():
 def default_params(**kw):
     """The reference's literals (MirtParams); keyword arguments override."""
     p = ffi.Params(max_bounces=128, sky_radiance=10.0, fixed_point_scale=1000.0,
-                   exposure=float(np.exp2(np.float32(-2.5))), shade_mode=0, rng_mode=0, seed=0x5EED0000, nee=0)
+                   exposure=float(np.exp2(np.float32(-2.5))), shade_mode=0, rng_mode=0, seed=0x5EED0000, nee=0,
+                   adaptive=0, reserved=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -135,6 +142,31 @@ class Scene:
                                       count.ctypes.data, C.byref(st), C.byref(frames))
         return sum4, count, st, frames.value
 
+    def render_active(self, camera, sources, width, height, params, first_sample, spp, active, sum4, count, moments,
+                      threads=0):
+        """spp samples for every source listed in `active` (None: all), added into sum4 / count / moments."""
+        n = len(sources)
+        act = None if active is None else np.ascontiguousarray(active, "<u4")
+        st = RenderStats()
+        lib().oracle_render_active(self._h, camera.ctypes.data, sources.ctypes.data, n, width, height, C.byref(params),
+                                   first_sample, spp, None if act is None else act.ctypes.data,
+                                   n if act is None else len(act), sum4.ctypes.data, count.ctypes.data,
+                                   None if moments is None else moments.ctypes.data, C.byref(st), threads)
+        return st
+
+    def wavefront_per_slot(self, camera, sources, width, height, params, slot_rng, sample_limit, n_frames, slots):
+        """The wavefront with one persistent random stream per slot (the reference's scheme)."""
+        n = len(sources)
+        rng = np.ascontiguousarray(slot_rng, "<u4").reshape(-1, 4)
+        assert len(rng) == slots
+        sum4 = np.zeros(4 * n, "<u4")
+        count = np.zeros(n, "<u4")
+        st = RenderStats()
+        lib().oracle_wavefront_per_slot(self._h, camera.ctypes.data, sources.ctypes.data, n, width, height,
+                                        C.byref(params), rng.ctypes.data, sample_limit, n_frames, slots,
+                                        sum4.ctypes.data, count.ctypes.data, C.byref(st))
+        return sum4, count, st
+
     def step_wavefront(self, camera, sources, width, height, params, first_sample, n_frames, slots):
         """Sums, counts and statistics after `n_frames` frames of the regenerating wavefront."""
         n = len(sources)
@@ -164,6 +196,12 @@ def _connect_rays(self, camera, sources, width, height, params, sample_no, bounc
 
 
 Scene.connect_rays = _connect_rays
+
+
+def adapt_update(count, moments, flags, rel_threshold, min_samples):
+    """Flags converged sources in place; returns the number still unflagged."""
+    return lib().oracle_adapt_update(count.ctypes.data, moments.ctypes.data, flags.ctypes.data, len(count),
+                                     rel_threshold, min_samples)
 
 
 def resolve(sum4, count, sources, width, height, params):

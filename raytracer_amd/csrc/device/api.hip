@@ -87,6 +87,9 @@ struct mirt_ctx {
   uint32_t next_sample = 0;  // sample number the next render call starts at
   uint32_t frame = 0;
   bool slots_seeded = false;
+  bool rng_seeded = false;   // per-slot streams: mirt_state_set_rng has been called
+  uint32_t stamp = 0;        // per-slot streams: last value written to DState::slot_stamp
+  uint32_t *d_active = nullptr;  // the list DState::active points at (owned by state_allocs)
 
   // diagnostics
   bool counting = false;
@@ -382,6 +385,7 @@ DFrameParams frame_params(mirt_ctx *c, unsigned long long sample_limit, uint32_t
   fp.frame = c->frame;
   fp.have_lights = c->sc.n_lights > 0 ? 1u : 0u;
   fp.counting = c->counting ? 1u : 0u;
+  fp.stamp = c->stamp;
   return fp;
 }
 
@@ -440,9 +444,15 @@ int seed_slots(mirt_ctx *c) {
 // in a material kernel.
 void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample, bool respawn) {
   const LaunchCfg cfg = launch_cfg(c);
+  const bool per_slot = c->params.rng_mode == MIRT_RNG_PER_SLOT;
+  if (per_slot) {
+    respawn = false;  // the sample stage alone pairs slots with sample numbers, in slot order
+    if (++c->stamp == 0u) c->stamp = 1u;
+  }
   DFrameParams fp = frame_params(c, sample_limit, first_sample);
   fp.respawn = respawn ? 1u : 0u;
-  timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
+  if (per_slot) timed_launch(c, K_SAMPLE, [&] { launch_sample_ordered(cfg, c->sc, c->st, fp); });
+  else timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
   if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
     timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
@@ -494,6 +504,8 @@ void mirt_default_params(MirtParams *out) {
   out->rng_mode = MIRT_RNG_PER_SAMPLE;
   out->seed = 0x5EED0000u;
   out->nee = 0;
+  out->adaptive = 0;
+  out->reserved = 0;
 }
 
 int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
@@ -841,7 +853,8 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   ENTER(ctx);
   if (!width || !height || !threads || !sources || !n_sources || !params)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: zero size or null pointer");
-  if (params->max_bounces == 0 || params->shade_mode > MIRT_SHADE_CLASSIC || params->rng_mode != MIRT_RNG_PER_SAMPLE)
+  if (params->max_bounces == 0 || params->shade_mode > MIRT_SHADE_CLASSIC || params->rng_mode > MIRT_RNG_PER_SLOT ||
+      params->adaptive > 1u)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: bad params");
   if (!(params->fixed_point_scale > 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: fixed_point_scale must be > 0");
   for (uint32_t i = 0; i < n_sources; ++i)
@@ -879,12 +892,119 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   HIP_TRY(ctx, hipMemset(st.stats, 0, S_COUNT * sizeof(unsigned long long)));
   HIP_TRY(ctx, hipMemset(st.qcount, 0, QW_COUNT * sizeof(uint32_t)));
   HIP_TRY(ctx, hipMemset(st.sample_index, 0, sizeof(unsigned long long)));
+  st.n_active = n_sources;
+  st.active = nullptr;
+  ctx->d_active = nullptr;
+  if ((rc = dev_alloc(ctx, own, &st.flags, n_sources)) != MIRT_OK) return rc;
+  HIP_TRY(ctx, hipMemset(st.flags, 0, (size_t)4 * n_sources));
+  if (params->adaptive) {
+    if ((rc = dev_alloc(ctx, own, &st.moments, (size_t)2 * n_sources)) != MIRT_OK) return rc;
+    HIP_TRY(ctx, hipMemset(st.moments, 0, (size_t)16 * n_sources));
+    if ((rc = dev_alloc(ctx, own, &ctx->d_active, n_sources)) != MIRT_OK) return rc;
+    // sources the caller hands over flagged are skipped from the start
+    std::vector<uint32_t> flags(n_sources), act;
+    bool any = false;
+    for (uint32_t i = 0; i < n_sources; ++i) {
+      flags[i] = sources[i].flags & 1u;
+      any = any || flags[i] != 0u;
+    }
+    if (any) {
+      for (uint32_t i = 0; i < n_sources; ++i)
+        if (!flags[i]) act.push_back(i);
+      HIP_TRY(ctx, hipMemcpy(st.flags, flags.data(), (size_t)4 * n_sources, hipMemcpyHostToDevice));
+      if (!act.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+      st.active = ctx->d_active;
+      st.n_active = (uint32_t)act.size();
+    }
+  }
+  if (params->rng_mode == MIRT_RNG_PER_SLOT) {
+    if ((rc = dev_alloc(ctx, own, &st.slot_stamp, threads)) != MIRT_OK) return rc;
+    HIP_TRY(ctx, hipMemset(st.slot_stamp, 0, (size_t)4 * threads));
+  }
   ctx->st = st;
   ctx->params = *params;
   ctx->have_state = true;
   ctx->next_sample = 0;
   ctx->frame = 0;
   ctx->slots_seeded = false;
+  ctx->rng_seeded = false;
+  ctx->stamp = 0;
+  return MIRT_OK;
+}
+
+int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (ctx->params.rng_mode != MIRT_RNG_PER_SLOT)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_set_rng: the state was created with per-sample streams");
+  if (!rng || n_slots != ctx->st.slots) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_set_rng: one uint4 per path slot");
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the stream state is the third 16-byte word of a slot's 48-byte path record
+  HIP_TRY(ctx, hipMemcpy2D(reinterpret_cast<unsigned char *>(ctx->st.path) + 32, sizeof(DPath), rng, 16, 16, n_slots,
+                           hipMemcpyHostToDevice));
+  ctx->rng_seeded = true;
+  ctx->slots_seeded = false;  // in-flight paths are dropped
+  return MIRT_OK;
+}
+
+int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (!ctx->params.adaptive) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: the state was created with adaptive = 0");
+  if (!(rel_threshold >= 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: rel_threshold must be >= 0");
+  const double thr2 = (double)rel_threshold * (double)rel_threshold;
+  launch_adapt_update(launch_cfg(ctx), ctx->st, thr2, min_samples);
+  HIP_TRY(ctx, hipGetLastError());
+  // Sample numbers already handed out must not come back under the new list:
+  // continue behind the highest one used so far.
+  unsigned long long handed = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&handed, ctx->st.sample_index, sizeof(handed), hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint32_t> flags(ctx->st.n_sources), act;
+  HIP_TRY(ctx, hipMemcpyAsync(flags.data(), ctx->st.flags, (size_t)4 * ctx->st.n_sources, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ev_collect(ctx);
+  if (ctx->slots_seeded && ctx->st.n_active != 0u) {  // mirt_step frames in flight: their numbering restarts
+    ctx->next_sample += (uint32_t)((handed + ctx->st.n_active - 1ull) / ctx->st.n_active);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.sample_index, 0, sizeof(unsigned long long), ctx->stream));
+  }
+  act.reserve(ctx->st.n_sources);
+  for (uint32_t i = 0; i < ctx->st.n_sources; ++i)
+    if ((flags[i] & 1u) == 0u) act.push_back(i);
+  if (act.size() == ctx->st.n_sources) {
+    ctx->st.active = nullptr;
+  } else {
+    if (!act.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+    ctx->st.active = ctx->d_active;
+  }
+  ctx->st.n_active = (uint32_t)act.size();
+  if (n_active) *n_active = ctx->st.n_active;
+  return MIRT_OK;
+}
+
+int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (!flags || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_flags: n_sources mismatch");
+  HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->st.flags, n_sources * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+int mirt_read_moments(mirt_ctx *ctx, uint64_t *moments, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state || !ctx->st.moments) return fail(ctx, MIRT_ERR_NOT_READY, "no state with adaptive = 1");
+  if (!moments || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_moments: n_sources mismatch");
+  HIP_TRY(ctx, hipMemcpyAsync(moments, ctx->st.moments, n_sources * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return MIRT_OK;
+}
+
+int mirt_write_moments(mirt_ctx *ctx, const uint64_t *moments, size_t n_sources) {
+  ENTER(ctx);
+  if (!ctx->have_state || !ctx->st.moments) return fail(ctx, MIRT_ERR_NOT_READY, "no state with adaptive = 1");
+  if (!moments || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "write_moments: n_sources mismatch");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->st.moments, moments, n_sources * 16, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
 }
 
@@ -904,6 +1024,11 @@ int mirt_reset_accum(mirt_ctx *ctx) {
   // the tail its integer work split leaves out.  Counts restart at 0, not 1.
   HIP_TRY(ctx, hipMemsetAsync(ctx->st.sum4, 0, (size_t)16 * ctx->st.n_sources, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->st.count, 0, (size_t)4 * ctx->st.n_sources, ctx->stream));
+  // ... and every source takes samples again (sample.slang:137 clears the flags)
+  HIP_TRY(ctx, hipMemsetAsync(ctx->st.flags, 0, (size_t)4 * ctx->st.n_sources, ctx->stream));
+  if (ctx->st.moments) HIP_TRY(ctx, hipMemsetAsync(ctx->st.moments, 0, (size_t)16 * ctx->st.n_sources, ctx->stream));
+  ctx->st.active = nullptr;
+  ctx->st.n_active = ctx->st.n_sources;
   ctx->next_sample = 0;
   ctx->slots_seeded = false;  // in-flight paths are dropped
   return MIRT_OK;
@@ -922,6 +1047,8 @@ static int check_ready(mirt_ctx *ctx) {
   if (!ctx->have_camera) return fail(ctx, MIRT_ERR_NOT_READY, "no camera set");
   if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && !ctx->have_classic_tables)
     return fail(ctx, MIRT_ERR_NOT_READY, "classic shading needs the per-material tables");
+  if (ctx->params.rng_mode == MIRT_RNG_PER_SLOT && !ctx->rng_seeded)
+    return fail(ctx, MIRT_ERR_NOT_READY, "per-slot random streams need mirt_state_set_rng");
   return MIRT_OK;
 }
 
@@ -929,6 +1056,7 @@ int mirt_step(mirt_ctx *ctx, uint32_t n_frames) {
   ENTER(ctx);
   int rc = check_ready(ctx);
   if (rc != MIRT_OK) return rc;
+  if (ctx->st.n_active == 0u) return MIRT_OK;  // every source has converged: nothing to trace
   if (!ctx->slots_seeded && (rc = seed_slots(ctx)) != MIRT_OK) return rc;
   // samples keep regenerating: no limit on the number handed out
   for (uint32_t f = 0; f < n_frames; ++f) run_frame(ctx, ~0ull, ctx->next_sample, false);
@@ -939,8 +1067,8 @@ int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
   ENTER(ctx);
   int rc = check_ready(ctx);
   if (rc != MIRT_OK) return rc;
-  if (spp == 0) return MIRT_OK;
-  const unsigned long long limit = (unsigned long long)ctx->st.n_sources * spp;
+  if (spp == 0 || ctx->st.n_active == 0u) return MIRT_OK;
+  const unsigned long long limit = (unsigned long long)ctx->st.n_active * spp;  // spp for every source that still takes samples
   const uint32_t first = ctx->next_sample;
   // paths left by mirt_step are dropped: every slot starts on a sample of this call
   ctx->frame = 0;

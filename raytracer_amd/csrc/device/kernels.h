@@ -50,6 +50,13 @@ struct DState {
   uint32_t *count;      // [n_sources]
   uint32_t *output;     // [width * height]
   uint32_t slots, n_sources, width, height;
+  // adaptive sampling (allocated when MirtParams.adaptive != 0, else null)
+  unsigned long long *moments;  // [2 * n_sources]: sum and sum of squares of the clamped fixed-point sample value
+  uint32_t *flags;              // [n_sources]: bit 0 = converged (SampleFlag::Converged)
+  const uint32_t *active;       // sources that still take samples, ascending; null = all of them
+  uint32_t n_active;            // entries of `active`; n_sources when it is null
+  // per-slot random streams (MIRT_RNG_PER_SLOT): the frame a slot was last seen on the terminate queue
+  uint32_t *slot_stamp;         // [slots], null in per-sample mode
 };
 
 struct DFrameParams {
@@ -61,6 +68,7 @@ struct DFrameParams {
   uint32_t have_lights;
   uint32_t counting;
   uint32_t respawn;  // paths that end in the extend epilogue are accumulated and respawned there
+  uint32_t stamp;    // per-slot mode: this frame's value in DState::slot_stamp (never 0)
 };
 
 // Threads per block of the streaming frame kernels (see block_push2).
@@ -100,6 +108,10 @@ inline dim3 stream_grid(const LaunchCfg &cfg, K kernel) {
 int trace_grid_blocks(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// per-slot random streams: the same stage with the slots of the terminate queue taking sample numbers in ascending slot order
+void launch_sample_ordered(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// flags[s] |= 1 where the standard error of source s's mean has fallen to rel_threshold of the mean
+void launch_adapt_update(const LaunchCfg &cfg, const DState &st, double threshold_squared, uint32_t min_samples);
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 // per-material shading: the extend epilogue (hit records, bounce count, routing to the material queues)
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);

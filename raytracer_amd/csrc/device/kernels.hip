@@ -57,6 +57,18 @@ __device__ __forceinline__ void accumulate_sample(const DState &st, const DFrame
   const bool o1 = add_saturating(sum + 1, to_fixed(rad.y, fp.p.fixed_point_scale));
   const bool o2 = add_saturating(sum + 2, to_fixed(rad.z, fp.p.fixed_point_scale));
   if (o0 || o1 || o2) atomicAdd(&st.stats[S_OVERFLOW], (unsigned long long)((o0 ? 1 : 0) + (o1 ? 1 : 0) + (o2 ? 1 : 0)));
+  if (st.moments != nullptr) {
+    // adaptive sampling: first and second moment of the sample's value y = r + g + b in fixed point,
+    // clamped to 24 bits so that 2^16 squares fit 64 bits — integers, so that sums from several
+    // GPUs add exactly (the reference declares a float4 sample_std for this, shaders/pathtracer.slang:31,
+    // and never writes it)
+    unsigned long long y = (unsigned long long)to_fixed(rad.x, fp.p.fixed_point_scale) +
+                           (unsigned long long)to_fixed(rad.y, fp.p.fixed_point_scale) +
+                           (unsigned long long)to_fixed(rad.z, fp.p.fixed_point_scale);
+    if (y > 0xFFFFFFull) y = 0xFFFFFFull;
+    atomicAdd(&st.moments[2 * (size_t)source], y);
+    atomicAdd(&st.moments[2 * (size_t)source + 1], y * y);
+  }
 }
 
 // camera basis (shaders/sample.slang:87-90)
@@ -80,17 +92,23 @@ __device__ __forceinline__ CamBasis cam_basis(const MirtCamera &cam) {
 // call starts in `slot`.
 __device__ __forceinline__ void spawn_sample(const DState &st, const DFrameParams &fp, const CamBasis &cb, uint32_t slot,
                                              unsigned long long si) {
+  // sample_idx % P (shaders/sample.slang:64-68) over the sources that still take
+  // samples: a source flagged Converged is skipped at spawn
+  // (shaders/archive/logic.slang:113-116) by not being on the list
   uint32_t source, k;
   if ((si >> 32) == 0ull) {
-    source = (uint32_t)si % st.n_sources;
-    k = (uint32_t)si / st.n_sources;
+    source = (uint32_t)si % st.n_active;
+    k = (uint32_t)si / st.n_active;
   } else {
-    source = (uint32_t)(si % st.n_sources);
-    k = (uint32_t)(si / st.n_sources);
+    source = (uint32_t)(si % st.n_active);
+    k = (uint32_t)(si / st.n_active);
   }
+  if (st.active != nullptr) source = st.active[source];
   k += fp.first_sample;
   const MirtSampleSource src = st.sources[source];
-  Rng rng = rng_init(fp.p.seed, source, k);
+  // per-sample streams are keyed by (seed, source, sample number); per-slot streams are the
+  // slot's own, seeded by the host and never re-seeded (shaders/random.slang:32-36)
+  Rng rng = fp.p.rng_mode == MIRT_RNG_PER_SLOT ? load_rng(st.path + slot) : rng_init(fp.p.seed, source, k);
   const float r1 = rng_next(rng);  // x jitter takes the first draw
   const float r2 = rng_next(rng);
   const float jx = r1 / (float)st.width, jy = r2 / (float)st.height;
@@ -174,6 +192,118 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
     st.qcount[W_EXTEND] = 0u;
     st.qcount[W_CONNECT] = 0u;
   }
+}
+
+// ---- the sample stage with per-slot random streams (MIRT_RNG_PER_SLOT)
+//
+// A slot's stream is its own, so which sample a slot takes next changes the
+// picture.  The reference leaves that to the arrival order of its atomics
+// (shaders/sample.slang:66, shaders/queue.slang:18,28): every pairing of the
+// slots that ended in a frame with the next sample numbers is a run it can make.
+// This picks ONE of them so that runs can be compared: the slots of the
+// terminate queue take the next sample numbers in ascending slot order.
+// k_mark_terminated (any grid) accumulates the finished samples and stamps the
+// slots; k_sample_ordered (ONE block) walks all slots in order, ranks the
+// stamped ones with a block scan and spawns.  Cost grows with the number of
+// slots on one CU: a mode for reference-faithful comparison runs, not for speed.
+__global__ __launch_bounds__(kStreamBlock) void k_mark_terminated(DState st, DFrameParams fp) {
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *term = st.qdata[Q_TERM0 + par];
+  const uint32_t count = st.qcount[Q_TERM0 + par];
+  unsigned long long finished = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const uint32_t slot = term[i];
+    DPath *pp = st.path + slot;
+    const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
+    if (source != kNoSample) {
+      accumulate_sample(st, fp, source, reinterpret_cast<const float4 *>(pp)[0]);
+      finished++;
+    }
+    st.slot_stamp[slot] = fp.stamp;
+  }
+  for (int off = 32; off > 0; off >>= 1) finished += __shfl_down(finished, off);
+  if (lane_id() == 0u && finished) atomicAdd(&st.stats[S_FINISHED], finished);
+}
+
+__global__ __launch_bounds__(kStreamBlock) void k_sample_ordered(DState st, DFrameParams fp) {
+  __shared__ uint32_t wave_count[16];
+  __shared__ uint32_t wave_spawn[16];
+  const uint32_t par = fp.frame & 1u;
+  uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const CamBasis cb = cam_basis(fp.cam);
+  const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+  unsigned long long next_sample = *st.sample_index;  // only this block touches it in this frame
+  uint32_t ext_count = st.qcount[Q_EXT0 + par];      // bounce rays pushed by the last frame's shade kernels
+  unsigned long long spawned = 0;
+  for (uint32_t base = 0; base < st.slots; base += kStreamBlock) {  // uniform
+    const uint32_t slot = base + tid;
+    const bool ended = slot < st.slots && st.slot_stamp[slot] == fp.stamp;
+    const unsigned long long m = __ballot(ended);
+    if (lane == 0u) wave_count[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+      const uint32_t c = wave_count[w];
+      if (w < wid) before += c;
+      total += c;
+    }
+    const unsigned long long si = next_sample + before + rank_in_mask(m);
+    const bool spawn = ended && si < fp.sample_limit;
+    if (spawn) {
+      spawn_sample(st, fp, cb, slot, si);
+      spawned++;
+    } else if (ended) {
+      reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+    }
+    // the spawned slots join the extension queue, still in slot order
+    const unsigned long long ms = __ballot(spawn);
+    if (lane == 0u) wave_spawn[wid] = (uint32_t)__popcll(ms);
+    __syncthreads();
+    uint32_t sbefore = 0, stotal = 0;
+    for (uint32_t w = 0; w < 16u; ++w) {
+      const uint32_t c = wave_spawn[w];
+      if (w < wid) sbefore += c;
+      stotal += c;
+    }
+    if (spawn) ext[ext_count + sbefore + rank_in_mask(ms)] = slot;
+    ext_count += stotal;
+    next_sample += total;
+    __syncthreads();
+  }
+  for (int off = 32; off > 0; off >>= 1) spawned += __shfl_down(spawned, off);
+  if (lane == 0u && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+  if (tid == 0u) {
+    *st.sample_index = next_sample;
+    st.qcount[Q_EXT0 + par] = ext_count;
+    // clear the counters of the queues that are idle during this kernel
+    st.qcount[Q_TERM0 + (par ^ 1u)] = 0u;
+    st.qcount[Q_EXT0 + (par ^ 1u)] = 0u;
+    st.qcount[Q_CONNECT] = 0u;
+    st.qcount[Q_LAMBERTIAN] = 0u;
+    st.qcount[Q_METALLIC] = 0u;
+    st.qcount[Q_DIELECTRIC] = 0u;
+    st.qcount[Q_EMISSIVE] = 0u;
+    st.qcount[W_EXTEND] = 0u;
+    st.qcount[W_CONNECT] = 0u;
+  }
+}
+
+// Adaptive sampling: source s counts as converged when it has at least
+// `min_samples` samples and the standard error of the mean of its sample value
+// y is at most rel_threshold times that mean:
+//   (n*S2 - S1^2) / (n^2 (n-1)) <= thr^2 * S1^2 / n^2   <=>   n*S2 - S1^2 <= thr^2 * S1^2 * (n-1)
+// with S1, S2 the integer moments; evaluated in IEEE doubles, operation by
+// operation (no contraction), so that a CPU gets the same flags.
+__global__ __launch_bounds__(256) void k_adapt_update(DState st, double thr2, uint32_t min_samples) {
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= st.n_sources) return;
+  const uint32_t n = st.count[s];
+  if (n < min_samples || n < 2u) return;
+  const double S1 = (double)st.moments[2 * (size_t)s], S2 = (double)st.moments[2 * (size_t)s + 1];
+  const double S1sq = S1 * S1;
+  const double lhs = (double)n * S2 - S1sq;
+  const double rhs = thr2 * S1sq * (double)(n - 1u);
+  if (lhs <= rhs) st.flags[s] |= 1u;
 }
 
 // Every slot starts on the terminate queue holding no sample, so the first
@@ -716,6 +846,16 @@ void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFramePara
 
 void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
   hipLaunchKernelGGL(k_sample, stream_grid(cfg, k_sample), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+}
+
+void launch_sample_ordered(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
+  hipLaunchKernelGGL(k_mark_terminated, stream_grid(cfg, k_mark_terminated), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+  hipLaunchKernelGGL(k_sample_ordered, dim3(1), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+}
+
+void launch_adapt_update(const LaunchCfg &cfg, const DState &st, double threshold_squared, uint32_t min_samples) {
+  hipLaunchKernelGGL(k_adapt_update, dim3((st.n_sources + 255u) / 256u), dim3(256), 0, cfg.stream, st, threshold_squared,
+                     min_samples);
 }
 
 // resident waves per SIMD the engine kernels are launched with (blocks per CU x waves per block / 4)

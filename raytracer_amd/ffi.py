@@ -46,6 +46,7 @@ assert Ray.itemsize == 32 and HitId.itemsize == 16
 NO_HIT = 0xFFFFFFFF
 NO_PRIM = 0x7FFFFFFF
 SHADE_UBER, SHADE_CLASSIC = 0, 1
+RNG_PER_SAMPLE, RNG_PER_SLOT = 0, 1
 MAT_LAMBERTIAN, MAT_METALLIC, MAT_DIELECTRIC, MAT_EMISSIVE = 1, 2, 3, 4
 
 
@@ -94,7 +95,7 @@ class Params(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("sky_radiance", C.c_float),
                 ("fixed_point_scale", C.c_float), ("exposure", C.c_float),
                 ("shade_mode", C.c_uint32), ("rng_mode", C.c_uint32), ("seed", C.c_uint32),
-                ("nee", C.c_uint32)]
+                ("nee", C.c_uint32), ("adaptive", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class TraversalCounts(C.Structure):
@@ -220,7 +221,8 @@ def host_lib():
 DEVICE_SYMBOLS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_status_string", "mirt_default_params",
     "mirt_scene_upload", "mirt_scene_update_instances", "mirt_state_create", "mirt_camera_set", "mirt_reset_accum",
-    "mirt_set_sample_range", "mirt_step", "mirt_render_spp", "mirt_synchronize", "mirt_read_output",
+    "mirt_set_sample_range", "mirt_state_set_rng", "mirt_adapt_update", "mirt_read_flags", "mirt_read_moments",
+    "mirt_write_moments", "mirt_step", "mirt_render_spp", "mirt_synchronize", "mirt_read_output",
     "mirt_read_accum", "mirt_copy_accum_to_device", "mirt_load_accum_from_device",
     "mirt_trace_closest", "mirt_trace_closest_static", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_bench_gather", "mirt_scene_bytes", "mirt_stats",
     "mirt_stats_reset", "mirt_set_counting", "mirt_set_event_timing", "mirt_dump_extension_rays",
@@ -253,6 +255,11 @@ def device_lib():
         L.mirt_camera_set.argtypes = [vp, vp]
         L.mirt_reset_accum.argtypes = [vp]
         L.mirt_set_sample_range.argtypes = [vp, u32]
+        L.mirt_state_set_rng.argtypes = [vp, vp, u32]
+        L.mirt_adapt_update.argtypes = [vp, C.c_float, u32, C.POINTER(u32)]
+        L.mirt_read_flags.argtypes = [vp, vp, sz]
+        L.mirt_read_moments.argtypes = [vp, vp, sz]
+        L.mirt_write_moments.argtypes = [vp, vp, sz]
         L.mirt_step.argtypes = [vp, u32]
         L.mirt_render_spp.argtypes = [vp, u32]
         L.mirt_synchronize.argtypes = [vp]

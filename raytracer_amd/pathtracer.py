@@ -90,6 +90,33 @@ class Pathtracer:
     def set_sample_range(self, first_sample):
         self._check(self._L.mirt_set_sample_range(self._h, first_sample), "mirt_set_sample_range")
 
+    def set_rng(self, rng):
+        """Per-slot random streams: one uint4 per path slot (the host's random_states vector)."""
+        rng = np.ascontiguousarray(rng, "<u4").reshape(-1, 4)
+        self._check(self._L.mirt_state_set_rng(self._h, rng.ctypes.data, len(rng)), "mirt_state_set_rng")
+
+    # ---- adaptive sampling ---------------------------------------------
+    def adapt_update(self, rel_threshold, min_samples):
+        """Flag converged sources; returns how many sources still take samples."""
+        n = C.c_uint32()
+        self._check(self._L.mirt_adapt_update(self._h, rel_threshold, min_samples, C.byref(n)), "mirt_adapt_update")
+        return n.value
+
+    def read_flags(self):
+        flags = np.zeros(self.n_sources, "<u4")
+        self._check(self._L.mirt_read_flags(self._h, flags.ctypes.data, self.n_sources), "mirt_read_flags")
+        return flags
+
+    def read_moments(self):
+        m = np.zeros(2 * self.n_sources, "<u8")
+        self._check(self._L.mirt_read_moments(self._h, m.ctypes.data, self.n_sources), "mirt_read_moments")
+        return m
+
+    def write_moments(self, moments):
+        m = np.ascontiguousarray(moments, "<u8")
+        assert m.size == 2 * self.n_sources
+        self._check(self._L.mirt_write_moments(self._h, m.ctypes.data, self.n_sources), "mirt_write_moments")
+
     # ---- rendering -----------------------------------------------------
     def step(self, n_frames=1):
         self._check(self._L.mirt_step(self._h, n_frames), "mirt_step")
