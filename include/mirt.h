@@ -84,7 +84,12 @@ typedef struct MirtTransform {
   float translation[4];
 } MirtTransform; /* 48 B */
 
-/* shaders/common.slang:7-18, src/material.rs:12-25 */
+/* shaders/common.slang:7-18, src/material.rs:12-25.  A texture id of 0 means
+ * "none" (the binder's own test is `emissive_texture > 0`, src/binder.rs:213-229);
+ * id t > 0 names textures[t - 1] of the scene.  colour_texture multiplies
+ * colour.rgb and emissive_texture multiplies emissive.rgb at the hit's
+ * interpolated vertex uv (glTF's factor x texture rule); the other two ids are
+ * carried and not read. */
 typedef struct MirtMaterial {
   uint32_t colour_texture;
   uint32_t emissive_texture;
@@ -157,6 +162,19 @@ typedef struct MirtClassicMaterialRef {
   uint32_t data;
 } MirtClassicMaterialRef; /* 8 B */
 
+/* A texture: width x height RGBA8 texels (R | G<<8 | B<<16 | A<<24, row by
+ * row, row 0 at v = 0) starting at texels[first_texel]; addressing repeats.
+ * The reference carries texture ids in Material and never binds a texture
+ * (src/material.rs:15-18; its glTF loader is commented out,
+ * src/scenes.rs:332-399), so the sampling rule is this library's:
+ * channel / 255, nearest or bilinear with texel centres at (i + 0.5) / size. */
+enum { MIRT_FILTER_NEAREST = 0, MIRT_FILTER_BILINEAR = 1 };
+typedef struct MirtTexture {
+  uint32_t width, height;
+  uint32_t first_texel;
+  uint32_t filter; /* MIRT_FILTER_* */
+} MirtTexture; /* 16 B */
+
 /* The ten read-only scene buffers in bind-group-0 order
  * (shaders/scene.slang:10-29; built by src/binder.rs:325-370 and
  * src/mesh.rs:198-284), plus the optional per-material tables. */
@@ -177,6 +195,9 @@ typedef struct MirtSceneDesc {
   const MirtMetallicData *metallic;           uint32_t n_metallic;
   const MirtDielectricData *dielectric;       uint32_t n_dielectric;
   const MirtEmissiveData *emissive;           uint32_t n_emissive;
+  /* textures named by MirtMaterial.colour_texture / emissive_texture; may be NULL/0 */
+  const MirtTexture *textures;                uint32_t n_textures;
+  const uint32_t *texels;                     uint32_t n_texels;
 } MirtSceneDesc;
 
 /* --------------------------------------------------------------- parameters */

@@ -43,6 +43,14 @@ int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t se
  * triangles).  File normals are dropped (computed normals, src/mesh.rs:357-413). */
 int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels,
                                uint32_t seed);
+/* A texture for MirtMaterial.colour_texture / emissive_texture: width x height
+ * RGBA8 texels, MIRT_FILTER_*.  Returns its 1-based id (0 in a material means
+ * none).  The reference has the ids and no texture store (src/material.rs:15-18). */
+int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter);
+/* Vertex uvs of a loaded mesh from two of its normalised position axes:
+ * uv = position[axis] * scale + offset.  (The reference uploads uv = 0 for
+ * every vertex, src/mesh.rs:241; so does this library until this is called.) */
+int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v, float scale, float offset);
 /* The sin / cos the procedural meshes are built with: IEEE +, -, * on doubles
  * only, so their vertices do not depend on the host's libm. */
 void mirth_det_sincos(double x, double *s_out, double *c_out);

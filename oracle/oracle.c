@@ -180,6 +180,15 @@ static int validate(const MirtSceneDesc *d) {
       if (r.kind > MIRT_MAT_EMISSIVE || (r.kind != MIRT_MAT_NONE && r.data >= lim)) return 0;
     }
   }
+  if (d->n_textures && (!d->textures || !d->texels)) return 0;
+  for (uint32_t i = 0; i < d->n_textures; ++i) {
+    const MirtTexture *t = &d->textures[i];
+    if (!t->width || !t->height || t->filter > MIRT_FILTER_BILINEAR ||
+        (uint64_t)t->first_texel + (uint64_t)t->width * t->height > d->n_texels)
+      return 0;
+  }
+  for (uint32_t i = 0; i < d->n_materials; ++i)
+    if (d->materials[i].colour_texture > d->n_textures || d->materials[i].emissive_texture > d->n_textures) return 0;
   return 1;
 }
 
@@ -204,6 +213,8 @@ oracle_scene *oracle_scene_create(const MirtSceneDesc *desc) {
   DUP(metallic, n_metallic, MirtMetallicData);
   DUP(dielectric, n_dielectric, MirtDielectricData);
   DUP(emissive, n_emissive, MirtEmissiveData);
+  DUP(textures, n_textures, MirtTexture);
+  DUP(texels, n_texels, uint32_t);
 #undef DUP
   s->M = (mat34 *)malloc(sizeof(mat34) * desc->n_instances);
   s->Mi = (mat34 *)malloc(sizeof(mat34) * desc->n_instances);
@@ -219,6 +230,7 @@ void oracle_scene_free(oracle_scene *s) {
   free((void *)s->d.transforms); free((void *)s->d.tlas_nodes); free((void *)s->d.tlas_to_instances);
   free((void *)s->d.light_sources); free((void *)s->d.classic_refs); free((void *)s->d.lambertian);
   free((void *)s->d.metallic); free((void *)s->d.dielectric); free((void *)s->d.emissive);
+  free((void *)s->d.textures); free((void *)s->d.texels);
   free(s->M); free(s->Mi); free(s);
 }
 
@@ -378,7 +390,7 @@ static int tlas_first_hit(const oracle_scene *s, v3 pos, v3 dir, uint32_t last_i
 
 /* The hit record extensionMain stores (shaders/ray_extend.slang:86-89,
  * 204-207): interpolated position and normal moved to world space. */
-typedef struct { v3 position, normal; uint32_t prim, inst, front_face; } hitrec;
+typedef struct { v3 position, normal; uint32_t prim, inst, front_face; float tu, tv; } hitrec;
 
 static void finish_hit(const oracle_scene *s, v3 world_dir, const besthit *b, hitrec *out) {
   const MirtInstance inst = s->d.instances[b->inst];
@@ -399,6 +411,48 @@ static void finish_hit(const oracle_scene *s, v3 world_dir, const besthit *b, hi
   out->front_face = dot3(out->normal, world_dir) < 0.0f;
   out->prim = b->prim;
   out->inst = b->inst;
+  /* texture coordinate: the vertex uvs interpolated like the normal */
+  out->tu = fmaf(v2->uv[0], v, fmaf(v1->uv[0], u, v0->uv[0] * w));
+  out->tv = fmaf(v2->uv[1], v, fmaf(v1->uv[1], u, v0->uv[1] * w));
+}
+
+/* ---------------------------------------------------------------- textures
+ * The reference carries texture ids in Material and binds no texture
+ * (src/material.rs:15-18), so the sampling rule is the build's own (mirt.h):
+ * RGBA8, channel / 255, repeat addressing, nearest or bilinear with texel
+ * centres at (i + 0.5) / size; id 0 = none, id t = textures[t - 1]. */
+static v3 texel_rgb(uint32_t t) {
+  return V3((float)(t & 255u) / 255.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f);
+}
+static v3 tex_sample(const oracle_scene *s, uint32_t id, float tu, float tv) {
+  const MirtTexture t = s->d.textures[id - 1u];
+  const uint32_t W = t.width, H = t.height;
+  const uint32_t *px = s->d.texels + t.first_texel;
+  const float fu = tu - floorf(tu), fv = tv - floorf(tv);
+  if (t.filter == MIRT_FILTER_NEAREST) {
+    const float xf = fu * (float)W, yf = fv * (float)H;
+    uint32_t x = xf >= 0.0f ? (uint32_t)xf : 0u, y = yf >= 0.0f ? (uint32_t)yf : 0u; /* NaN: texel 0 */
+    if (x >= W) x = W - 1u;
+    if (y >= H) y = H - 1u;
+    return texel_rgb(px[(size_t)y * W + x]);
+  }
+  const float sx = fu * (float)W - 0.5f, sy = fv * (float)H - 0.5f;
+  const float x0f = floorf(sx), y0f = floorf(sy);
+  const float tx = sx - x0f, ty = sy - y0f;
+  const int xi = (x0f >= -1.0f) ? (int)x0f : 0, yi = (y0f >= -1.0f) ? (int)y0f : 0;
+  const uint32_t x0 = xi < 0 ? W - 1u : ((uint32_t)xi >= W ? W - 1u : (uint32_t)xi);
+  const uint32_t y0 = yi < 0 ? H - 1u : ((uint32_t)yi >= H ? H - 1u : (uint32_t)yi);
+  const uint32_t x1 = x0 + 1u == W ? 0u : x0 + 1u, y1 = y0 + 1u == H ? 0u : y0 + 1u;
+  const v3 c00 = texel_rgb(px[(size_t)y0 * W + x0]), c10 = texel_rgb(px[(size_t)y0 * W + x1]);
+  const v3 c01 = texel_rgb(px[(size_t)y1 * W + x0]), c11 = texel_rgb(px[(size_t)y1 * W + x1]);
+  const float ax = 1.0f - tx, ay = 1.0f - ty;
+  const v3 top = V3(c00.x * ax + c10.x * tx, c00.y * ax + c10.y * tx, c00.z * ax + c10.z * tx);
+  const v3 bot = V3(c01.x * ax + c11.x * tx, c01.y * ax + c11.y * tx, c01.z * ax + c11.z * tx);
+  return V3(top.x * ay + bot.x * ty, top.y * ay + bot.y * ty, top.z * ay + bot.z * ty);
+}
+/* 1,1,1 or the texel the hit sees through texture `id` */
+static v3 hit_texel(const oracle_scene *s, uint32_t id, const hitrec *h) {
+  return id != 0u && id <= s->d.n_textures ? tex_sample(s, id, h->tu, h->tv) : V3(1.0f, 1.0f, 1.0f);
 }
 
 static void add_counts(MirtTraversalCounts *dst, const tcounts *c, uint64_t rays) {
@@ -622,7 +676,18 @@ static v3 material_brdf(v3 wi, v3 wo, v3 n, const MirtMaterial *m) {
 static int shade_uber(const oracle_scene *s, path *p) {
   const v3 wo = p->ray_dir; /* the incoming direction, not negated */
   const MirtInstance inst = s->d.instances[p->hit.inst];
-  const MirtMaterial *mat = &s->d.materials[inst.material];
+  MirtMaterial textured = s->d.materials[inst.material];
+  if (textured.colour_texture != 0u) { /* base-colour texture x colour factor */
+    const v3 c = hit_texel(s, textured.colour_texture, &p->hit);
+    textured.colour[0] = textured.colour[0] * c.x; textured.colour[1] = textured.colour[1] * c.y;
+    textured.colour[2] = textured.colour[2] * c.z;
+  }
+  if (textured.emissive_texture != 0u) {
+    const v3 c = hit_texel(s, textured.emissive_texture, &p->hit);
+    textured.emissive[0] = textured.emissive[0] * c.x; textured.emissive[1] = textured.emissive[1] * c.y;
+    textured.emissive[2] = textured.emissive[2] * c.z;
+  }
+  const MirtMaterial *mat = &textured;
   p->rad = add3(p->rad, mul3(p->throughput, ld3(mat->emissive)));
   v3 n = scale3(p->hit.normal, p->hit.front_face != 0 ? 1.0f : -1.0f);
   (void)cosine_hemisphere_sample(n, p->rng); /* diffuse_sample: value unused, draws kept */

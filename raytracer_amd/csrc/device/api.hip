@@ -70,6 +70,7 @@ struct mirt_ctx {
   // scene
   bool have_scene = false;
   bool have_classic_tables = false;  // the scene came with classic_refs (per-material shading can run)
+  bool textured_light = false;       // a listed light's material has an emissive texture
   DScene sc{};
   std::vector<void *> scene_allocs;     // geometry: nodes + triangles, normals
   std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
@@ -256,6 +257,19 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
   if (!no_lights)
     for (uint32_t i = 0; i < d->n_light_sources; ++i)
       if (d->light_sources[i] >= d->n_instances) return bad("light source instance out of range");
+  if (d->n_textures) {
+    if (!d->textures || !d->texels) return bad("textures without texels");
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+      const MirtTexture &t = d->textures[i];
+      if (t.width == 0 || t.height == 0 || t.width > 65536u || t.height > 65536u) return bad("texture size must be 1..65536");
+      if (t.filter > MIRT_FILTER_BILINEAR) return bad("unknown texture filter");
+      if ((unsigned long long)t.first_texel + (unsigned long long)t.width * t.height > d->n_texels)
+        return bad("texture texels out of range");
+    }
+  }
+  for (uint32_t i = 0; i < d->n_materials; ++i)
+    if (d->materials[i].colour_texture > d->n_textures || d->materials[i].emissive_texture > d->n_textures)
+      return bad("material names a texture the scene does not have");
   if (d->n_classic_refs) {
     if (d->n_classic_refs != d->n_materials || !d->classic_refs) return bad("classic_refs must have one entry per material");
     for (uint32_t i = 0; i < d->n_classic_refs; ++i) {
@@ -729,6 +743,28 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   if ((rc = dev_alloc(ctx, ctx->scene_allocs, &ptn, d->n_indices)) != MIRT_OK) return rc;
   if (d->n_indices) HIP_TRY(ctx, hipMemcpy(ptn, trins.get(), (size_t)d->n_indices * sizeof(DTriN), hipMemcpyHostToDevice));
   sc.trin = ptn;
+  sc.tri_uv = nullptr;
+  if (d->n_textures) {
+    // the three vertex uvs of every triangle, two float4 per triangle
+    std::unique_ptr<float[]> uvs(new float[(size_t)8 * (d->n_indices ? d->n_indices : 1)]);
+    for (uint32_t g = 0; g < d->n_geometries; ++g) {
+      const MirtGeometryOffsets &o = d->geometry_offsets[g];
+      const uint32_t idx_end = g + 1 == d->n_geometries ? d->n_indices : d->geometry_offsets[g + 1].index;
+      for (uint32_t p = o.index; p < idx_end; ++p) {
+        float *q = uvs.get() + (size_t)8 * p;
+        for (int k = 0; k < 3; ++k) {
+          const MirtVertex &v = d->vertices[o.vertex + d->indices[p].v[k]];
+          q[2 * k] = v.uv[0];
+          q[2 * k + 1] = v.uv[1];
+        }
+        q[6] = q[7] = 0.0f;
+      }
+    }
+    float *puv = nullptr;
+    if ((rc = dev_alloc(ctx, ctx->scene_allocs, &puv, (size_t)8 * d->n_indices)) != MIRT_OK) return rc;
+    if (d->n_indices) HIP_TRY(ctx, hipMemcpy(puv, uvs.get(), (size_t)32 * d->n_indices, hipMemcpyHostToDevice));
+    sc.tri_uv = reinterpret_cast<const float4 *>(puv);
+  }
   return MIRT_OK;
 }
 
@@ -783,7 +819,25 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       m.roughness = d->materials[i].roughness;
       m.ior = d->materials[i].ior;
       m.transmission = d->materials[i].transmission;
+      m.tex[0] = d->materials[i].colour_texture;
+      m.tex[1] = d->materials[i].emissive_texture;
       mats[i] = m;
+    }
+    {
+      std::vector<uint4> tex(d->n_textures);
+      for (uint32_t i = 0; i < d->n_textures; ++i)
+        tex[i] = uint4{d->textures[i].width, d->textures[i].height, d->textures[i].first_texel, d->textures[i].filter};
+      std::vector<uint32_t> texels;
+      if (d->n_textures) texels.assign(d->texels, d->texels + d->n_texels);
+      if ((rc = dev_upload(ctx, own, &sc.textures, tex)) != MIRT_OK) return rc;
+      if ((rc = dev_upload(ctx, own, &sc.texels, texels)) != MIRT_OK) return rc;
+      sc.n_textures = d->n_textures;
+    }
+    // light sampling reads a light's emission from its per-material row, not through a texture
+    ctx->textured_light = false;
+    for (uint32_t i = 0; i < d->n_light_sources; ++i) {
+      const uint32_t li = d->light_sources[i];
+      if (li != 0xFFFFFFFFu && d->materials[d->instances[li].material].emissive_texture != 0u) ctx->textured_light = true;
     }
     if ((rc = dev_upload(ctx, own, &sc.mat, mats)) != MIRT_OK) return rc;
     const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
@@ -832,7 +886,10 @@ int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
   if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
   // a different set of geometries, or a TLAS that outgrew its block: start over
-  if (d->n_geometries != ctx->n_geometries || d->n_tlas_nodes > ctx->tlas_capacity) return mirt_scene_upload(ctx, d);
+  // (so does a first texture: the per-triangle uvs are built from the geometry arrays, which must then be valid)
+  if (d->n_geometries != ctx->n_geometries || d->n_tlas_nodes > ctx->tlas_capacity ||
+      (d->n_textures != 0 && ctx->sc.tri_uv == nullptr))
+    return mirt_scene_upload(ctx, d);
   std::string why;
   if (!validate_instances(d, why)) return fail(ctx, MIRT_ERR_BAD_SCENE, why);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1047,6 +1104,10 @@ static int check_ready(mirt_ctx *ctx) {
   if (!ctx->have_camera) return fail(ctx, MIRT_ERR_NOT_READY, "no camera set");
   if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && !ctx->have_classic_tables)
     return fail(ctx, MIRT_ERR_NOT_READY, "classic shading needs the per-material tables");
+  if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && ctx->params.nee && ctx->textured_light)
+    return fail(ctx, MIRT_ERR_NOT_READY,
+                "light sampling (nee) does not read emissive textures: a listed light has one; render with nee = 0 "
+                "or uber shading");
   if (ctx->params.rng_mode == MIRT_RNG_PER_SLOT && !ctx->rng_seeded)
     return fail(ctx, MIRT_ERR_NOT_READY, "per-slot random streams need mirt_state_set_rng");
   return MIRT_OK;

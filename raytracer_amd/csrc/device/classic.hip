@@ -34,6 +34,7 @@ struct SlotIn {
   v3 rdir;
   v3 hpos, hn;  // hit position, normal flipped to face the ray
   uint32_t inst, ff;
+  float tu, tv;  // texture coordinate of the hit (scenes with textures only)
 };
 
 // RAW: the hit record still holds what the traversal left (u, v, triangle, instance) and the world-space record of extensionMain
@@ -55,6 +56,8 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
   v3 rpos;
   uint32_t li, lp;
   load_ray(st.ray, slot, rpos, s.rdir, li, lp);
+  s.tu = __uint_as_float(li);  // !RAW: left there by k_extend_finish when the scene has textures
+  s.tv = __uint_as_float(lp);
   const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
   v3 hn;
   if (RAW) {
@@ -67,6 +70,7 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
     best.inst = __float_as_uint(raw.w);
     finish_hit(sc, s.rdir, best, s.hpos, hn, s.ff);
     s.inst = best.inst;
+    if (sc.tri_uv != nullptr) hit_uv(sc, best, s.tu, s.tv);
   } else {
     const float4 ha = h4[0], hb = h4[1];
     const uint32_t inst_ff = __float_as_uint(ha.w);
@@ -253,11 +257,18 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
       const DInst *inst = &sc.inst[s.inst];
       v3 new_pos = s.hpos, new_dir = s.rdir;
       v3 thr = V3(s.pb.x, s.pb.y, s.pb.z), rad = V3(s.pa.x, s.pa.y, s.pa.z);
+      // the instance's live material may name a texture: it multiplies this kernel's albedo
+      // (the emissive texture for the emissive kernel, the colour texture for the others)
+      v3 texel = V3(1.0f, 1.0f, 1.0f);
+      if (sc.tri_uv != nullptr) {
+        const uint32_t tex = sc.mat[inst->material].tex[KIND == MIRT_MAT_EMISSIVE ? 1 : 0];
+        if (tex != 0u) texel = tex_sample(sc, tex, s.tu, s.tv);
+      }
       if (KIND == MIRT_MAT_LAMBERTIAN) {
         // process_material<LambertianData> (archive/material.slang:17-139,
         // archive/lambertian.slang:26-35)
         const float *ad = sc.lambertian + 4 * (size_t)inst->kind_data;
-        const v3 albedo = V3(ad[0], ad[1], ad[2]);
+        const v3 albedo = V3(ad[0] * texel.x, ad[1] * texel.y, ad[2] * texel.z);
         const v3 nf = s.hn;
         const v3 wo = neg3(s.rdir);
         // scatter draws three values but stores the state after the second
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
         const float *md = sc.metallic + 8 * (size_t)inst->kind_data;
         const v3 nf = s.hn;
         new_pos = add3(s.hpos, scale3(nf, 0.005f));
-        thr = mul3(thr, V3(md[0], md[1], md[2]));
+        thr = mul3(thr, V3(md[0] * texel.x, md[1] * texel.y, md[2] * texel.z));
         const v3 dir = s.rdir;
         const v3 reflected = sub3(dir, scale3(nf, 2.0f * dot3(dir, nf)));
         const float a = rng_next(s.rng), b = rng_next(s.rng), c = rng_next(s.rng);
@@ -339,13 +350,13 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
           scv = add3(perp, par_v);
           new_pos = sub3(s.hpos, scale3(nf, 1e-4f));
         }
-        thr = mul3(thr, V3(dd[0], dd[1], dd[2]));
+        thr = mul3(thr, V3(dd[0] * texel.x, dd[1] * texel.y, dd[2] * texel.z));
         new_dir = normalize3(scv);
         alive = true;
       } else {
         // archive/emissive.slang:42-59
         const float *ed = sc.emissive + 4 * (size_t)inst->kind_data;
-        rad = add3(rad, mul3(V3(ed[0], ed[1], ed[2]), thr));
+        rad = add3(rad, mul3(V3(ed[0] * texel.x, ed[1] * texel.y, ed[2] * texel.z), thr));
         alive = false;
       }
       s.pa.x = rad.x; s.pa.y = rad.y; s.pa.z = rad.z;

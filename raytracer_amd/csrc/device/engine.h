@@ -600,4 +600,54 @@ __device__ __forceinline__ void finish_hit(const DScene &sc, v3 world_dir, const
   front_face = dot3(normal, world_dir) < 0.0f ? 1u : 0u;
 }
 
+// ---------------------------------------------------------------- textures
+// The hit's texture coordinate: the vertex uvs interpolated like the normal
+// (shaders/ray_extend.slang:86-88 interpolates position and normal this way;
+// the live shader leaves uv at the barycentrics because its host never fills
+// Vertex.uv, src/mesh.rs:241).
+__device__ __forceinline__ void hit_uv(const DScene &sc, const BestHit &b, float &tu, float &tv) {
+  const float4 *q = sc.tri_uv + 2 * (size_t)(sc.inst[b.inst].tri_base + b.prim);
+  const float4 a = q[0], c = q[1];
+  const float u = b.u, v = b.v, w = 1.0f - u - v;
+  tu = __builtin_fmaf(c.x, v, __builtin_fmaf(a.z, u, a.x * w));
+  tv = __builtin_fmaf(c.y, v, __builtin_fmaf(a.w, u, a.y * w));
+}
+
+__device__ __forceinline__ v3 texel_rgb(uint32_t t) {
+  return V3((float)(t & 255u) / 255.0f, (float)((t >> 8) & 255u) / 255.0f, (float)((t >> 16) & 255u) / 255.0f);
+}
+
+// Texture `id` (1-based) at (tu, tv): repeat addressing, nearest or bilinear
+// with texel centres at (i + 0.5) / size, channels / 255, every operation in
+// the order written here (the CPU restatement writes the same).
+__device__ __forceinline__ v3 tex_sample(const DScene &sc, uint32_t id, float tu, float tv) {
+  const uint4 t = sc.textures[id - 1u];
+  const uint32_t W = t.x, H = t.y;
+  const uint32_t *px = sc.texels + t.z;
+  const float fu = tu - __builtin_floorf(tu), fv = tv - __builtin_floorf(tv);  // [0, 1); NaN stays NaN
+  if (t.w == MIRT_FILTER_NEAREST) {
+    // a NaN coordinate converts to texel 0
+    uint32_t x = (uint32_t)(fu * (float)W), y = (uint32_t)(fv * (float)H);
+    if (!(fu * (float)W >= 0.0f)) x = 0u;
+    if (!(fv * (float)H >= 0.0f)) y = 0u;
+    if (x >= W) x = W - 1u;
+    if (y >= H) y = H - 1u;
+    return texel_rgb(px[(size_t)y * W + x]);
+  }
+  const float sx = fu * (float)W - 0.5f, sy = fv * (float)H - 0.5f;
+  const float x0f = __builtin_floorf(sx), y0f = __builtin_floorf(sy);
+  const float tx = sx - x0f, ty = sy - y0f;
+  // x0f is in [-1, W - 1]; -1 wraps to the last column (NaN: column 0)
+  int xi = (x0f >= -1.0f) ? (int)x0f : 0, yi = (y0f >= -1.0f) ? (int)y0f : 0;
+  const uint32_t x0 = xi < 0 ? W - 1u : ((uint32_t)xi >= W ? W - 1u : (uint32_t)xi);
+  const uint32_t y0 = yi < 0 ? H - 1u : ((uint32_t)yi >= H ? H - 1u : (uint32_t)yi);
+  const uint32_t x1 = x0 + 1u == W ? 0u : x0 + 1u, y1 = y0 + 1u == H ? 0u : y0 + 1u;
+  const v3 c00 = texel_rgb(px[(size_t)y0 * W + x0]), c10 = texel_rgb(px[(size_t)y0 * W + x1]);
+  const v3 c01 = texel_rgb(px[(size_t)y1 * W + x0]), c11 = texel_rgb(px[(size_t)y1 * W + x1]);
+  const float ax = 1.0f - tx, ay = 1.0f - ty;
+  const v3 top = V3(c00.x * ax + c10.x * tx, c00.y * ax + c10.y * tx, c00.z * ax + c10.z * tx);
+  const v3 bot = V3(c01.x * ax + c11.x * tx, c01.y * ax + c11.y * tx, c01.z * ax + c11.z * tx);
+  return V3(top.x * ay + bot.x * ty, top.y * ay + bot.y * ty, top.z * ay + bot.z * ty);
+}
+
 }  // namespace mirt

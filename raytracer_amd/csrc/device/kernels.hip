@@ -452,6 +452,13 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
           finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
           h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
           h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
+          if (sc.tri_uv != nullptr) {
+            // the material kernel's texture coordinate rides in the ray's two exclusion words,
+            // which nothing reads between this kernel and the material kernel's own store
+            float tu, tv;
+            hit_uv(sc, best, tu, tv);
+            reinterpret_cast<float4 *>(st.ray + slot)[1] = make_float4(rb.x, rb.y, tu, tv);
+          }
         }
         if (RAW) {
           // the material kernel counts the bounce; here the slot only finds its queue
@@ -596,13 +603,26 @@ __device__ __forceinline__ v3 material_brdf(v3 wi, v3 wo, v3 n, const DMaterial 
 // given in registers: emission, the three sampling draws, throughput update,
 // the bounce ray.  Returns whether the path goes on.
 __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &st, uint32_t slot, v3 wo, v3 hit_pos,
-                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim, float4 &rad_out,
-                                                uint32_t &source_out) {
+                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim, const BestHit &best,
+                                                float4 &rad_out, uint32_t &source_out) {
   float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
   float4 pa = p4[0], pb = p4[1];
   const float4 pr = p4[2];
   Rng rng{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)};
-  const DMaterial mat = sc.mat[sc.inst[inst].material];
+  DMaterial mat = sc.mat[sc.inst[inst].material];
+  if ((mat.tex[0] | mat.tex[1]) != 0u) {
+    // base-colour and emissive textures multiply the material's factors (src/material.rs:12-25)
+    float tu, tv;
+    hit_uv(sc, best, tu, tv);
+    if (mat.tex[0] != 0u) {
+      const v3 c = tex_sample(sc, mat.tex[0], tu, tv);
+      mat.colour[0] = mat.colour[0] * c.x; mat.colour[1] = mat.colour[1] * c.y; mat.colour[2] = mat.colour[2] * c.z;
+    }
+    if (mat.tex[1] != 0u) {
+      const v3 c = tex_sample(sc, mat.tex[1], tu, tv);
+      mat.emissive[0] = mat.emissive[0] * c.x; mat.emissive[1] = mat.emissive[1] * c.y; mat.emissive[2] = mat.emissive[2] * c.z;
+    }
+  }
 
   // s.rad += s.throughput * mat.emissive.rgb
   pa.x = pa.x + pb.x * mat.emissive[0];
@@ -695,7 +715,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
         uint32_t li, lp, ff;
         load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
         finish_hit(sc, wo, best, hp, hn, ff);
-        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim, rad, source);
+        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim, best, rad, source);
         shaded++;
       }
     }

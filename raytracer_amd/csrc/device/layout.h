@@ -135,7 +135,7 @@ struct DMaterial {  // the fields of MirtMaterial the kernels read
   float colour[4];
   float emissive[4];
   float metallic, roughness, ior, transmission;
-  float pad[4];
+  uint32_t tex[4];  // colour texture, emissive texture (0 = none, t = textures[t - 1]), unused, unused
 };
 static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 
@@ -159,6 +159,11 @@ struct DScene {
   const float *metallic;      // 8 floats per row (albedo, fuzz, pad)
   const float *dielectric;    // 8 floats per row (albedo, ir, pad)
   const float *emissive;      // 4 floats per row (albedo)
+  // textures (all null / 0 when the scene has none)
+  const float4 *tri_uv;       // two float4 per triangle: (u0, v0, u1, v1), (u2, v2, -, -)
+  const uint4 *textures;      // MirtTexture rows: width, height, first texel, filter
+  const uint32_t *texels;     // RGBA8
+  uint32_t n_textures;
 };
 
 struct DCounts {

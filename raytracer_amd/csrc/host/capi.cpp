@@ -213,6 +213,31 @@ int mirth_set_dragon_standin(mirth_scene *s, int kind, uint32_t levels) {
   return 0;
 }
 
+int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter) {
+  if (!s || !rgba8 || width == 0 || height == 0 || width > 65536u || height > 65536u || filter > MIRT_FILTER_BILINEAR)
+    return -1;
+  if (s->scene.texels.size() + (size_t)width * height > 0xFFFFFFFFull) return -1;
+  MirtTexture t{width, height, (uint32_t)s->scene.texels.size(), filter};
+  s->scene.texels.insert(s->scene.texels.end(), rgba8, rgba8 + (size_t)width * height);
+  s->scene.textures.push_back(t);
+  s->bound = false;
+  return (int)s->scene.textures.size();  // 1-based: 0 means "no texture" in a material
+}
+
+int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v, float scale, float offset) {
+  if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size() || axis_u < 0 || axis_u > 2 || axis_v < 0 || axis_v > 2)
+    return -1;
+  MeshData &d = s->scene.meshes[(size_t)mesh_id];
+  d.uvs.resize(2 * d.mesh.positions.size());
+  for (size_t i = 0; i < d.mesh.positions.size(); ++i) {
+    const float *p = &d.mesh.positions[i].x;
+    d.uvs[2 * i] = p[axis_u] * scale + offset;
+    d.uvs[2 * i + 1] = p[axis_v] * scale + offset;
+  }
+  s->bound = false;
+  return 0;
+}
+
 int mirth_add_material(mirth_scene *s, const MirtMaterial *m) {
   if (!s || !m) return -1;
   return (int)s->scene.add_material(*m);

@@ -93,6 +93,9 @@ struct MeshData {
   std::vector<MirtBVHNode> nodes;
   Mesh mesh;
   AABB aabb;
+  // texture coordinates, two per vertex; empty = all zero, which is what the
+  // reference uploads for every mesh (src/mesh.rs:241)
+  std::vector<float> uvs;
 };
 
 // src/tlas.rs:20-159
@@ -141,6 +144,9 @@ struct Scene {
   std::unordered_map<std::string, uint32_t> by_desc;
   // MaterialServer
   std::vector<MirtMaterial> material_server;
+  // textures the materials name by 1-based id (the reference has ids and no texture store, src/material.rs:15-18)
+  std::vector<MirtTexture> textures;
+  std::vector<uint32_t> texels;
   // entities in spawn order
   std::vector<Entity> entities;
 

@@ -90,6 +90,10 @@ void Scene::regenerate_buffer() {  // src/mesh.rs:198-284
       memset(&v, 0, sizeof(v));
       memcpy(v.position, &md.mesh.positions[i], 16);
       memcpy(v.normal, &md.mesh.normals[i], 16);
+      if (2 * i + 1 < md.uvs.size()) {
+        v.uv[0] = md.uvs[2 * i];
+        v.uv[1] = md.uvs[2 * i + 1];
+      }
       vertices.push_back(v);
     }
     for (size_t f = 0; f < md.mesh.n_faces(); ++f) {
@@ -201,6 +205,8 @@ void Scene::fill_desc(MirtSceneDesc &d) const {
   d.metallic = metallic.data();                   d.n_metallic = (uint32_t)metallic.size();
   d.dielectric = dielectric.data();               d.n_dielectric = (uint32_t)dielectric.size();
   d.emissive = emissive.data();                   d.n_emissive = (uint32_t)emissive.size();
+  d.textures = textures.data();                   d.n_textures = (uint32_t)textures.size();
+  d.texels = texels.data();                       d.n_texels = (uint32_t)texels.size();
 }
 
 // ------------------------------------------------------------------- scenes

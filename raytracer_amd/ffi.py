@@ -35,6 +35,8 @@ MetallicData = np.dtype([("albedo", "<f4", 4), ("fuzz", "<f4"), ("pad", "<u4", 3
 DielectricData = np.dtype([("albedo", "<f4", 4), ("ir", "<f4"), ("pad", "<u4", 3)])
 EmissiveData = np.dtype([("albedo", "<f4", 4)])
 ClassicMaterialRef = np.dtype([("kind", "<u4"), ("data", "<u4")])
+Texture = np.dtype([("width", "<u4"), ("height", "<u4"), ("first_texel", "<u4"), ("filter", "<u4")])
+FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 Ray = np.dtype([("pos", "<f4", 3), ("dir", "<f4", 3), ("last_inst", "<u4"), ("last_prim", "<u4")])
 HitId = np.dtype([("instance_id", "<u4"), ("triangle_id", "<u4"), ("t", "<f4"), ("front_face", "<u4")])
 
@@ -68,6 +70,8 @@ class SceneDesc(C.Structure):
         ("metallic", C.c_void_p), ("n_metallic", C.c_uint32),
         ("dielectric", C.c_void_p), ("n_dielectric", C.c_uint32),
         ("emissive", C.c_void_p), ("n_emissive", C.c_uint32),
+        ("textures", C.c_void_p), ("n_textures", C.c_uint32),
+        ("texels", C.c_void_p), ("n_texels", C.c_uint32),
     ]
 
 
@@ -88,6 +92,8 @@ SCENE_ARRAYS = [
     ("metallic", "n_metallic", MetallicData),
     ("dielectric", "n_dielectric", DielectricData),
     ("emissive", "n_emissive", EmissiveData),
+    ("textures", "n_textures", Texture),
+    ("texels", "n_texels", np.dtype("<u4")),
 ]
 
 
@@ -196,6 +202,8 @@ def host_lib():
         L.mirth_load_mesh_knot.argtypes = [vp, u32, u32, u32]
         L.mirth_load_mesh_subdivided.argtypes = [vp, C.c_char_p, C.c_char_p, u32, u32]
         L.mirth_set_dragon_standin.argtypes = [vp, i32, u32]
+        L.mirth_add_texture.argtypes = [vp, u32, u32, vp, u32]
+        L.mirth_mesh_set_planar_uv.argtypes = [vp, i32, i32, i32, C.c_float, C.c_float]
         L.mirth_det_sincos.restype = None
         L.mirth_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mirth_add_material.argtypes = [vp, vp]

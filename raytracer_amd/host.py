@@ -51,8 +51,10 @@ def make_transform(scale=(1, 1, 1), rotation=(0, 0, 0), translation=(0, 0, 0)):
 
 
 def make_material(colour=(0.8, 0.8, 0.8, 1.0), emissive=(0, 0, 0, 0), metallic=0.0, roughness=1.0,
-                  ior=1.5, transmission=0.0):
+                  ior=1.5, transmission=0.0, colour_texture=0, emissive_texture=0):
     m = default_material()
+    m["colour_texture"] = colour_texture
+    m["emissive_texture"] = emissive_texture
     m["colour"][0] = colour
     m["emissive"][0] = emissive
     m["metallic"] = metallic
@@ -161,6 +163,17 @@ class Scene:
         self._check(self._L.mirth_mesh_copy(self._h, mesh_id, pos.ctypes.data, nrm.ctypes.data,
                                             faces.ctypes.data, nodes.ctypes.data), "mesh_copy")
         return pos, nrm, faces, nodes
+
+    # textures -----------------------------------------------------------
+    def add_texture(self, rgba8, filter=ffi.FILTER_BILINEAR):
+        """rgba8[h, w] packed texels (R | G<<8 | B<<16 | A<<24); returns the 1-based texture id."""
+        t = np.ascontiguousarray(rgba8, "<u4")
+        h, w = t.shape
+        return self._check(self._L.mirth_add_texture(self._h, w, h, t.ctypes.data, filter), "add_texture")
+
+    def set_planar_uv(self, mesh_id, axis_u=0, axis_v=1, scale=0.5, offset=0.5):
+        """uv = position[axis] * scale + offset for every vertex of a loaded mesh."""
+        self._check(self._L.mirth_mesh_set_planar_uv(self._h, mesh_id, axis_u, axis_v, scale, offset), "set_planar_uv")
 
     # MaterialServer -----------------------------------------------------
     def add_material(self, material):
