@@ -1472,8 +1472,9 @@ struct mirt_group {
   std::vector<mirt_ctx *> members;
   std::string error;
   uint32_t next_sample = 0;  // the group's sample-number cursor
-  // staging for the reduction, on member 0's device
-  uint32_t *tmp_sum4 = nullptr, *tmp_count = nullptr;
+  // staging for the reduction, on member 0's device: one copy of the accumulators per other member
+  std::vector<uint32_t *> tmp_sum4, tmp_count;
+  std::vector<hipEvent_t> copied;  // member i's copies into its staging have been issued up to here
   size_t tmp_sources = 0;
 };
 
@@ -1500,9 +1501,10 @@ int for_members(mirt_group *g, const char *what, F call) {
 void group_free_staging(mirt_group *g) {
   if (g->members.empty()) return;
   if (hipSetDevice(g->members[0]->device) != hipSuccess) return;
-  if (g->tmp_sum4) (void)hipFree(g->tmp_sum4);
-  if (g->tmp_count) (void)hipFree(g->tmp_count);
-  g->tmp_sum4 = g->tmp_count = nullptr;
+  for (uint32_t *p : g->tmp_sum4) (void)hipFree(p);
+  for (uint32_t *p : g->tmp_count) (void)hipFree(p);
+  g->tmp_sum4.clear();
+  g->tmp_count.clear();
   g->tmp_sources = 0;
 }
 
@@ -1566,6 +1568,7 @@ int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group)
 int mirt_group_destroy(mirt_group *g) {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   group_free_staging(g);
+  for (hipEvent_t ev : g->copied) (void)hipEventDestroy(ev);
   for (mirt_ctx *m : g->members) (void)mirt_destroy(m);
   delete g;
   return MIRT_OK;
@@ -1639,39 +1642,58 @@ int mirt_group_reduce(mirt_group *g) {
   mirt_ctx *root = g->members[0];
   if (!root->have_state) return gfail(g, MIRT_ERR_NOT_READY, "reduce: no state");
   const size_t ns = root->st.n_sources;
-  for (size_t i = 1; i < g->members.size(); ++i)
+  const size_t n = g->members.size();
+  for (size_t i = 1; i < n; ++i)
     if (!g->members[i]->have_state || g->members[i]->st.n_sources != ns)
       return gfail(g, MIRT_ERR_NOT_READY, "reduce: member " + std::to_string(i) + " has no state of the same size");
-  if (g->members.size() == 1) return MIRT_OK;
+  if (n == 1) return MIRT_OK;
 #define GROUP_TRY(expr)                                                                  \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess) return gfail(g, MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
   GROUP_TRY(hipSetDevice(root->device));
-  if (g->tmp_sources != ns) {
+  if (g->tmp_sources != ns || g->tmp_sum4.size() != n - 1) {
     group_free_staging(g);
     GROUP_TRY(hipSetDevice(root->device));
-    GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&g->tmp_sum4), ns * 16));
-    GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&g->tmp_count), ns * 4));
+    for (size_t i = 1; i < n; ++i) {
+      uint32_t *a = nullptr, *b = nullptr;
+      GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&a), ns * 16));
+      g->tmp_sum4.push_back(a);
+      GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&b), ns * 4));
+      g->tmp_count.push_back(b);
+    }
     g->tmp_sources = ns;
   }
-  for (size_t i = 1; i < g->members.size(); ++i) {
+  while (g->copied.size() < n - 1) {
+    hipEvent_t ev;
+    GROUP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g->copied.push_back(ev);
+  }
+  // Every member pushes its accumulators to its own staging area on member 0's
+  // device, on its own stream (behind whatever it still has in flight), and
+  // clears them behind the copy: the n - 1 transfers run side by side over
+  // their own links.  Member 0's stream waits for each copy's event and adds.
+  for (size_t i = 1; i < n; ++i) {
     mirt_ctx *c = g->members[i];
-    // the member's own work is complete (render calls synchronise); make sure of it
     GROUP_TRY(hipSetDevice(c->device));
-    GROUP_TRY(hipStreamSynchronize(c->stream));
-    GROUP_TRY(hipSetDevice(root->device));
-    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum4, root->device, c->st.sum4, c->device, ns * 16, root->stream));
-    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_count, root->device, c->st.count, c->device, ns * 4, root->stream));
-    launch_accum_add(launch_cfg(root), root->st.sum4, g->tmp_sum4, ns * 4);
-    launch_accum_add(launch_cfg(root), root->st.count, g->tmp_count, ns);
-    GROUP_TRY(hipGetLastError());
-    GROUP_TRY(hipStreamSynchronize(root->stream));
-    GROUP_TRY(hipSetDevice(c->device));
+    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum4[i - 1], root->device, c->st.sum4, c->device, ns * 16, c->stream));
+    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_count[i - 1], root->device, c->st.count, c->device, ns * 4, c->stream));
+    GROUP_TRY(hipEventRecord(g->copied[i - 1], c->stream));
     GROUP_TRY(hipMemsetAsync(c->st.sum4, 0, ns * 16, c->stream));
     GROUP_TRY(hipMemsetAsync(c->st.count, 0, ns * 4, c->stream));
-    GROUP_TRY(hipStreamSynchronize(c->stream));
+  }
+  GROUP_TRY(hipSetDevice(root->device));
+  for (size_t i = 1; i < n; ++i) {
+    GROUP_TRY(hipStreamWaitEvent(root->stream, g->copied[i - 1], 0));
+    launch_accum_add(launch_cfg(root), root->st.sum4, g->tmp_sum4[i - 1], ns * 4, true);
+    launch_accum_add(launch_cfg(root), root->st.count, g->tmp_count[i - 1], ns, false);
+  }
+  GROUP_TRY(hipGetLastError());
+  GROUP_TRY(hipStreamSynchronize(root->stream));
+  for (size_t i = 1; i < n; ++i) {
+    GROUP_TRY(hipSetDevice(g->members[i]->device));
+    GROUP_TRY(hipStreamSynchronize(g->members[i]->stream));
   }
 #undef GROUP_TRY
   return MIRT_OK;

@@ -757,19 +757,26 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
 // ---------------------------------------------------------- accumulator add
 
 // dst += src, four words per thread (both arrays hold a multiple of four words
-// or end with a scalar tail).
+// or end with a scalar tail).  SATURATE: a sum that would pass 2^32 - 1 stays
+// there, as in accumulate_sample, so that the total of several devices is what
+// one device would have accumulated.
+template <bool SATURATE>
 __global__ __launch_bounds__(256) void k_accum_add(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n) {
+  auto add = [](uint32_t a, uint32_t b) {
+    const uint32_t r = a + b;
+    return (SATURATE && r < a) ? 0xFFFFFFFFu : r;
+  };
   const size_t i = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
   if (i + 4u <= n) {
     uint4 a = *reinterpret_cast<const uint4 *>(dst + i);
     const uint4 b = *reinterpret_cast<const uint4 *>(src + i);
-    a.x += b.x;
-    a.y += b.y;
-    a.z += b.z;
-    a.w += b.w;
+    a.x = add(a.x, b.x);
+    a.y = add(a.y, b.y);
+    a.z = add(a.z, b.z);
+    a.w = add(a.w, b.w);
     *reinterpret_cast<uint4 *>(dst + i) = a;
   } else {
-    for (size_t k = i; k < n; ++k) dst[k] += src[k];
+    for (size_t k = i; k < n; ++k) dst[k] = add(dst[k], src[k]);
   }
 }
 
@@ -928,10 +935,12 @@ void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DSta
   else hipLaunchKernelGGL((k_finish_shade_uber<false>), stream_grid(cfg, k_finish_shade_uber<false>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
-void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n) {
+void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n, bool saturate) {
   if (n == 0) return;
   const size_t threads = (n + 3u) / 4u;
-  hipLaunchKernelGGL(k_accum_add, dim3((unsigned)((threads + 255u) / 256u)), dim3(256), 0, cfg.stream, dst, src, n);
+  const dim3 grid((unsigned)((threads + 255u) / 256u));
+  if (saturate) hipLaunchKernelGGL(k_accum_add<true>, grid, dim3(256), 0, cfg.stream, dst, src, n);
+  else hipLaunchKernelGGL(k_accum_add<false>, grid, dim3(256), 0, cfg.stream, dst, src, n);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {

@@ -857,3 +857,70 @@ def test_axis_aligned_rays_from_box_planes_nan_semantics(pt):
     want_any, wca = sc.trace_any(rays, tmax, True)
     got_any, gca = pt.trace_any(rays, tmax, True)
     assert hits_equal(got_any, want_any) and gca.as_dict() == wca.as_dict()
+
+
+def test_group_on_two_distinct_devices_when_the_box_has_them(config_scenes):
+    """The peer copies of mirt_group_reduce between two different GPUs (skipped on a one-GPU box)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    arrays, info = config_scenes(1)
+    W, H = 96, 64
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=4, seed=info.seed)
+    with pathtracer.PathtracerGroup([0, 1]) as grp:
+        grp.upload_scene(arrays)
+        grp.create_state(W, H, 3000, src, prm)
+        grp.set_camera(cam)
+        grp.render_spp(5)
+        grp.reduce()
+        s5, c5 = grp.read_accum()
+    o4, oc, _ = po.Scene(arrays).render(cam, src, W, H, po.default_params(max_bounces=4, seed=info.seed), 0, 5)
+    assert np.array_equal(s5, o4) and np.array_equal(c5, oc)
+
+
+def test_radiance_sums_saturate_and_report_instead_of_wrapping(pt, config_scenes):
+    # configuration 5's scene at its own fixed-point scale, 64 samples per pixel on a 256 x 256
+    # image: no sum comes near 32 bits, and the statistic says so
+    arrays, info = config_scenes(5, dragon_n_u=96, dragon_n_v=24)
+    pt.upload_scene(arrays)
+    W = H = 256
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=8, seed=info.seed, shade_mode=1, nee=1)
+    pt.create_state(W, H, W * H * 4, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(64)
+    s4, cnt = pt.read_accum()
+    assert pt.stats().overflowed_sums == 0 and cnt.min() == 64
+    # largest sum x (1024 / 64) stays below 2^32: configuration 5's 1024 spp fit too
+    assert int(s4.max()) * 16 < 2 ** 32
+    # a light 4e5 times brighter: sums reach the limit, stay there in any order of the adds (the
+    # oracle, sequential, ends on the same bits) and the statistic is non-zero on both sides
+    arrays1, info1 = config_scenes(1)
+    hot = {k: v.copy() for k, v in arrays1.items()}
+    hot["materials"]["emissive"] *= np.float32(4e5)
+    pt.upload_scene(hot)
+    W = H = 48
+    src = host.make_sample_sources(W, H, 3)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(max_bounces=4, seed=3)
+    pt.create_state(W, H, 700, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(24)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, wst = po.Scene(hot).render(cam, src, W, H, po.default_params(max_bounces=4, seed=3), 0, 24)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+    assert (s4 == 0xFFFFFFFF).sum() > 10 and pt.stats().overflowed_sums > 0 and wst.overflowed_sums > 0
+    # two contexts' sums that overflow only when added: the group reduction saturates too
+    with pathtracer.PathtracerGroup([0, 0]) as grp:
+        grp.upload_scene(hot)
+        grp.create_state(W, H, 700, src, prm)
+        grp.set_camera(cam)
+        grp.render_spp(24)
+        grp.reduce()
+        g4, gcnt = grp.read_accum()
+    assert np.array_equal(g4, w4) and np.array_equal(gcnt, wcnt)
