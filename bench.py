@@ -350,7 +350,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
-        geometry = GEOMETRY[info.procedural_dragon]
+        geometry = GEOMETRY[info.procedural_dragon] if args.config >= 3 else "the reference's own assets (suzanne / teapot)"
         out = {
             "metric": "Mrays/s (extend+shadow), dragon 1080p",
             "value": rays / elapsed / 1e6,
