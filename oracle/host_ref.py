@@ -149,3 +149,70 @@ def nodes_as_records(nodes):
     """(lb3, ub3, left, skip, is_leaf, start, end) tuples, the fields of BVHNodeGPU."""
     return [(tuple(float(x) for x in n.lb), tuple(float(x) for x in n.ub), int(n.left), int(n.skip),
              int(n.is_leaf), int(n.start), int(n.end)) for n in nodes]
+
+
+# ---------------------------------------------------------------------- TLAS
+# src/tlas.rs:61-158 with glam 0.30's Mat4 semantics written out: column-major
+# 4x4 of f32; from_rotation_x/y/z put (cos, sin) / (-sin, cos) in the two
+# rotated columns; a * b multiplies a by every column of b; a * v is
+# x*col0 + y*col1 + z*col2 + w*col3, each product rounded, summed left to right.
+def _mat_identity():
+    return [np.array([1, 0, 0, 0], f32), np.array([0, 1, 0, 0], f32), np.array([0, 0, 1, 0], f32),
+            np.array([0, 0, 0, 1], f32)]
+
+
+def _mul_vec4(m, v):
+    acc = m[0] * v[0]
+    acc = acc + m[1] * v[1]
+    acc = acc + m[2] * v[2]
+    acc = acc + m[3] * v[3]
+    return acc
+
+
+def _mul_mat4(a, b):
+    return [_mul_vec4(a, col) for col in b]
+
+
+def instance_matrix(scale, rotation, translation, sin, cos):
+    """translate * (rot_x * (rot_y * rot_z)) * scale (src/tlas.rs:80-92); sin / cos are f32 functions."""
+    t = _mat_identity()
+    t[3] = np.array([translation[0], translation[1], translation[2], 1], f32)
+    sx, cx, sy, cy, sz, cz = sin(rotation[0]), cos(rotation[0]), sin(rotation[1]), cos(rotation[1]), sin(rotation[2]), cos(rotation[2])
+    rx, ry, rz = _mat_identity(), _mat_identity(), _mat_identity()
+    rx[1] = np.array([0, cx, sx, 0], f32)
+    rx[2] = np.array([0, -sx, cx, 0], f32)
+    ry[0] = np.array([cy, 0, -sy, 0], f32)
+    ry[2] = np.array([sy, 0, cy, 0], f32)
+    rz[0] = np.array([cz, sz, 0, 0], f32)
+    rz[1] = np.array([-sz, cz, 0, 0], f32)
+    rotate = _mul_mat4(rx, _mul_mat4(ry, rz))
+    s = _mat_identity()
+    s[0][0], s[1][1], s[2][2] = f32(scale[0]), f32(scale[1]), f32(scale[2])
+    return _mul_mat4(t, _mul_mat4(rotate, s))
+
+
+def build_tlas(geom_aabbs, transforms, instances, sin, cos):
+    """TLAS::new: geom_aabbs[g] = (lb3, ub3); transforms[t] = (scale3, rotation3, translation3);
+    instances[i] = (transform, geometry).  Returns (nodes, instance_ids)."""
+    boxes = []
+    for t_idx, g_idx in instances:
+        lb, ub = geom_aabbs[g_idx]
+        m = instance_matrix(*transforms[t_idx], sin, cos)
+        acc = None
+        for x in (0, 1):           # multi_cartesian_product: the last factor varies fastest
+            for y in (0, 1):
+                for z in (0, 1):
+                    corner = np.array([lb[0] if x == 0 else ub[0], lb[1] if y == 0 else ub[1],
+                                       lb[2] if z == 0 else ub[2], 1.0], f32)
+                    c = _mul_vec4(m, corner)[:3]
+                    acc = (c, c) if acc is None else (np.minimum(acc[0], c), np.maximum(acc[1], c))
+        boxes.append(acc)
+    ids = list(range(len(instances)))
+
+    def swap(a, b):
+        boxes[a], boxes[b] = boxes[b], boxes[a]
+        ids[a], ids[b] = ids[b], ids[a]
+
+    b = Builder(len(instances), lambda e: boxes[e], lambda e: (boxes[e][0] + boxes[e][1]) / f32(2.0), swap)
+    b.initialize(1)
+    return b.nodes, ids

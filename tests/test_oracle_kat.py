@@ -1161,3 +1161,30 @@ def test_procedural_meshes_use_their_own_trigonometry_and_have_pinned_bits():
     assert info.procedural_dragon == 2 and len(arrays["indices"]) == 12 + 15488 + 2
     arrays, info = host.build_config_scene(3, dragon_n_u=64, dragon_n_v=16)
     assert info.procedural_dragon == 1 and len(arrays["indices"]) == 12 + 2 * 64 * 16 + 2
+
+
+def test_tlas_of_the_host_library_against_the_python_restatement(config_scenes):
+    # TLAS::new (src/tlas.rs:61-158): eight corners of every instance's BLAS root box through
+    # translate * (Rx * (Ry * Rz)) * scale with glam's column-major products, then the same
+    # builder with leaves of one — rebuilt from the flat buffers by an independent restatement
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    sin = lambda x: np.float32(libm.sinf(float(x)))
+    cos = lambda x: np.float32(libm.cosf(float(x)))
+    for cfg, kw in ((2, {}), (3, dict(dragon_n_u=48, dragon_n_v=12)), (4, dict(dragon_n_u=48, dragon_n_v=12))):
+        arrays, _ = config_scenes(cfg, **kw)
+        inst = arrays["instances"]
+        roots = arrays["blas_nodes"][arrays["geometry_offsets"]["blas_node"]]
+        geom_aabbs = [(r["lb"][:3].copy(), r["ub"][:3].copy()) for r in roots]
+        transforms = [(t["scale"][:3], t["rotation"][:3], t["translation"][:3]) for t in arrays["transforms"]]
+        want_nodes, want_ids = arrays["tlas_nodes"], arrays["tlas_to_instances"]
+        nodes, ids = host_ref.build_tlas(geom_aabbs, transforms, [(int(i["transform"]), int(i["geometry"])) for i in inst],
+                                         sin, cos)
+        assert ids == want_ids.tolist()
+        got = host_ref.nodes_as_records(nodes)
+        assert len(got) == len(want_nodes)
+        for g, w in zip(got, want_nodes):
+            assert g == (tuple(float(x) for x in w["lb"][:3]), tuple(float(x) for x in w["ub"][:3]), int(w["left"]),
+                         int(w["right"]), int(w["is_leaf"]), int(w["start"]), int(w["end"]))
