@@ -453,6 +453,21 @@ int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions
                     uint32_t *faces4, uint32_t n_faces, MirtBVHNode *nodes,
                     uint32_t nodes_capacity, uint32_t *n_nodes, float *device_ms);
 
+/* TLAS::new (src/tlas.rs:61-158) on the device, for binder_system's "regenerate the
+ * TLAS when transforms or meshes changed" (src/binder.rs:257-282): the world box of
+ * every instance from the eight corners of its geometry's box — geom_aabbs6 holds
+ * (lb.xyz, ub.xyz) of each BLAS root, MeshServer::aabbs() — through
+ * translate * (Rx * (Ry * Rz)) * scale, then the builder with leaves of one
+ * instance.  nodes (capacity 2 * n_instances always suffices) and
+ * instance_ids[n_instances] (TLAS::instance_ids, binding 8) come out byte-identical
+ * to the host builder's; the matrices are formed on the host with its sin / cos, the
+ * boxes and the tree on the device.  Synchronises. */
+int mirt_build_tlas(mirt_ctx *ctx, const float *geom_aabbs6, uint32_t n_geometries,
+                    const MirtTransform *transforms, uint32_t n_transforms,
+                    const MirtInstance *instances, uint32_t n_instances, MirtBVHNode *nodes,
+                    uint32_t nodes_capacity, uint32_t *n_nodes, uint32_t *instance_ids,
+                    float *device_ms);
+
 /* ------------------------------------------------- several GPUs, one process */
 
 /* A group is one context per device ordinal, driven from one host thread of

@@ -1536,6 +1536,37 @@ int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions
   return MIRT_OK;
 }
 
+int mirt_build_tlas(mirt_ctx *ctx, const float *geom_aabbs6, uint32_t n_geometries, const MirtTransform *transforms,
+                    uint32_t n_transforms, const MirtInstance *instances, uint32_t n_instances, MirtBVHNode *nodes,
+                    uint32_t nodes_capacity, uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms) {
+  ENTER(ctx);
+  if (!geom_aabbs6 || !transforms || !instances || !nodes || !n_nodes || !instance_ids || n_instances == 0 || nodes_capacity == 0)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_tlas: null argument or no instances");
+  if (n_instances > (1u << 30)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_tlas: too many instances");
+  if (device_ms) *device_ms = 0.0f;
+  // M = translate * (Rx * (Ry * Rz)) * scale (src/tlas.rs:80-92) per instance on the host — its sin / cos
+  // are the ones the reference's glam calls — as a column-major 4x4
+  std::vector<float> mats((size_t)16 * n_instances);
+  std::vector<uint32_t> geom(n_instances);
+  for (uint32_t i = 0; i < n_instances; ++i) {
+    if (instances[i].transform >= n_transforms || instances[i].geometry >= n_geometries)
+      return fail(ctx, MIRT_ERR_BAD_SCENE, "build_tlas: instance refers to a missing transform or geometry");
+    float M[12], Mi[12];
+    instance_matrices(transforms[instances[i].transform], M, Mi);
+    float *c = &mats[(size_t)16 * i];
+    for (int col = 0; col < 4; ++col)
+      for (int r = 0; r < 3; ++r) c[4 * col + r] = M[4 * r + col];
+    c[3] = c[7] = c[11] = 0.0f;
+    c[15] = 1.0f;
+    geom[i] = instances[i].geometry;
+  }
+  std::string err;
+  const int rc = build_tlas_device(ctx->stream, geom_aabbs6, n_geometries, mats.data(), geom.data(), n_instances, nodes,
+                                   nodes_capacity, n_nodes, instance_ids, device_ms, &ctx->build_ws, &ctx->build_ws_bytes, err);
+  if (rc != MIRT_OK) return fail(ctx, rc, err);
+  return MIRT_OK;
+}
+
 int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group) {
   if (!device_ordinals || n < 1 || !out_group) return MIRT_ERR_INVALID_ARGUMENT;
   *out_group = nullptr;

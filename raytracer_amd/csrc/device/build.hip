@@ -78,9 +78,11 @@ struct BuildBufs {
   uint32_t *chunk_r;        // R's in the chunk, then (after the scan) R's before it in its node
   uint32_t *chunk_lb;       // L's behind the chunk in its node
   uint32_t nf;
+  uint32_t leaf_max;        // nodes of up to this many elements stay leaves: 4 for a BLAS, 1 for the TLAS
 };
 
-constexpr uint32_t kLeafMax = 4u;      // BLAS::new: initialize(4)
+constexpr uint32_t kBlasLeafMax = 4u;   // BLAS::new: initialize(4) (src/blas.rs:75)
+constexpr uint32_t kTlasLeafMax = 1u;   // TLAS::new: initialize(1) (src/tlas.rs:130)
 constexpr uint32_t kBigNode = MIRT_BUILD_BIG;   // nodes this big get a 1024-thread block
 #ifndef MIRT_BUILD_TINY
 #define MIRT_BUILD_TINY 16u
@@ -263,6 +265,40 @@ __global__ __launch_bounds__(256) void k_build_prep(BuildBufs bb) {
   bb.perm[f] = f;
 }
 
+// TLAS::new's elements (src/tlas.rs:61-99): the world box of every instance from the eight
+// corners of its geometry's box through M = translate * (Rx * (Ry * Rz)) * scale — M comes
+// from the host, column-major, built there with the host's own sin / cos so that it has the
+// host builder's bits — each corner as x*col0 + y*col1 + z*col2 + w*col3 summed left to
+// right, united in the order x, y, z (z fastest); elem_centroid = (lb + ub) / 2 (src/tlas.rs:32-34).
+__global__ __launch_bounds__(256) void k_tlas_prep(BuildBufs bb, const float *geom_aabbs6, const float *mats16,
+                                                   const uint32_t *inst_geometry) {
+  const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= bb.nf) return;
+  const float *a = geom_aabbs6 + 6 * (size_t)inst_geometry[e];
+  const float *m = mats16 + 16 * (size_t)e;
+  float lb[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
+  bool first = true;
+  for (int x = 0; x <= 1; ++x)
+    for (int y = 0; y <= 1; ++y)
+      for (int z = 0; z <= 1; ++z) {
+        const float v[4] = {x == 0 ? a[0] : a[3], y == 0 ? a[1] : a[4], z == 0 ? a[2] : a[5], 1.0f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float acc = m[r] * v[0];
+          acc = acc + m[4 + r] * v[1];
+          acc = acc + m[8 + r] * v[2];
+          acc = acc + m[12 + r] * v[3];
+          lb[r] = first ? acc : hmin2(lb[r], acc);
+          ub[r] = first ? acc : hmax2(ub[r], acc);
+        }
+        first = false;
+      }
+  bb.bmn[e] = make_float4(lb[0], lb[1], lb[2], 0.0f);
+  bb.bmx[e] = make_float4(ub[0], ub[1], ub[2], 0.0f);
+  bb.cen[e] = make_float4((lb[0] + ub[0]) / 2.0f, (lb[1] + ub[1]) / 2.0f, (lb[2] + ub[2]) / 2.0f, 0.0f);
+  bb.perm[e] = e;
+}
+
 // the root: a leaf over every face (src/blas.rs:64-71) with its box; the box keys of
 // kBuildChunk faces per block meet in root_keys (all ones before the launch)
 __global__ __launch_bounds__(1024) void k_build_root_keys(BuildBufs bb, unsigned long long *root_keys) {
@@ -373,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_build_split(BuildBufs bb, uint32_t first
   const uint32_t id = first + blockIdx.x;
   const TNode node = bb.tn[id];
   const uint32_t s = node.s, n = node.e - node.s;
-  if (n <= kLeafMax) return;
+  if (n <= bb.leaf_max) return;
   if ((NT == 1024) != (n >= kBigNode) || n >= kHugeNode || n <= kTinyNode) return;
   const uint32_t tid = threadIdx.x;
 
@@ -483,7 +519,7 @@ __global__ __launch_bounds__(256) void k_build_split_tiny(BuildBufs bb, uint32_t
   const uint32_t id = first + t;
   const TNode node = bb.tn[id];
   const uint32_t s = node.s, e = node.e, n = e - s;
-  if (n <= kLeafMax || n > kTinyNode) return;
+  if (n <= bb.leaf_max || n > kTinyNode) return;
   const int axis = split_axis(node);
   auto centroid = [&](uint32_t p) {
     const float4 c = bb.cen[bb.perm[p]];
@@ -858,11 +894,79 @@ struct Carver {
     }                                                                \
   } while (0)
 
+// The tree over the prepared elements (boxes, centroids, identity order in bb): root, level
+// loop, then the reference's numbering and skip links into d_out.  `n_elems` = bb.nf.
+static int grow_tree(hipStream_t stream, BuildBufs &bb, uint32_t n_faces, size_t cap, size_t max_huge, size_t max_chunks,
+                     unsigned long long *root_keys, MirtBVHNode *d_out, uint32_t *total_out, std::string &err) {
+  BUILD_TRY(hipMemsetAsync(root_keys, 0xFF, 6 * sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kBuildChunk - 1u) / kBuildChunk), dim3(1024), 0, stream, bb, root_keys);
+  hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, stream, bb, root_keys);
+
+  // grow the tree one level at a time; a level is the run of nodes the previous one created
+  std::vector<std::pair<uint32_t, uint32_t>> levels;  // first id, count
+  uint32_t big_now = 0, huge_now = 0, wave_now = 0;
+  uint32_t first = 0, count = 1, big_seen = 0, huge_seen = 0, wave_seen = 0;
+  while (count != 0u) {
+    levels.push_back({first, count});
+    uint32_t tot[4] = {0, 0, 0, 0};
+    if (levels.size() == 1) {
+      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
+      BUILD_TRY(hipStreamSynchronize(stream));
+    } else {
+      tot[1] = big_now;
+      tot[2] = huge_now;
+      tot[3] = wave_now;
+    }
+    // the shapes for big nodes only when this level holds a node of their size class
+    if (tot[2] != huge_seen) {
+      const dim3 cgrid((unsigned)max_chunks), ngrid((unsigned)((max_huge + 255) / 256));
+      hipLaunchKernelGGL(k_huge_list, dim3(1), dim3(1024), 0, stream, bb, first, count);
+      hipLaunchKernelGGL(k_huge_range, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_count, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_scan, ngrid, dim3(256), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_tables, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_place, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_copy, cgrid, dim3(1024), 0, stream, bb);
+      hipLaunchKernelGGL(k_huge_finish, ngrid, dim3(256), 0, stream, bb);
+    }
+    huge_seen = tot[2];
+    if (tot[1] != big_seen) hipLaunchKernelGGL((k_build_split<1024>), dim3(count), dim3(1024), 0, stream, bb, first);
+    big_seen = tot[1];
+    if (tot[3] != wave_seen) hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
+    wave_seen = tot[3];
+    hipLaunchKernelGGL(k_build_split_tiny, dim3((count + 255u) / 256u), dim3(256), 0, stream, bb, first, count);
+    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipStreamSynchronize(stream));
+    const uint32_t total = tot[0];
+    big_now = tot[1];
+    huge_now = tot[2];
+    wave_now = tot[3];
+    if (total > cap || total < first + count) {
+      err = "build: node count out of range";
+      return MIRT_ERR_HIP;
+    }
+    first += count;
+    count = total - first;
+    if (levels.size() > (size_t)n_faces + 2) {
+      err = "build: the tree is deeper than it can be";
+      return MIRT_ERR_HIP;
+    }
+  }
+  const uint32_t total = first;
+  for (size_t l = levels.size(); l-- > 0;)
+    hipLaunchKernelGGL(k_build_up, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second);
+  for (size_t l = 0; l < levels.size(); ++l)
+    hipLaunchKernelGGL(k_build_down, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second, d_out);
+  *total_out = total;
+  return MIRT_OK;
+}
+
 int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_positions, uint32_t *faces4,
                       uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
                       float *device_ms, void **workspace, size_t *workspace_bytes, std::string &err) {
   BuildBufs bb{};
   bb.nf = n_faces;
+  bb.leaf_max = kBlasLeafMax;
   float4 *d_pos = nullptr;
   uint4 *d_faces = nullptr;
   MirtBVHNode *d_out = nullptr;
@@ -925,65 +1029,11 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
 
   const unsigned fblocks = (n_faces + 255u) / 256u;
   hipLaunchKernelGGL(k_build_prep, dim3(fblocks), dim3(256), 0, stream, bb);
-  BUILD_TRY(hipMemsetAsync(root_keys, 0xFF, 6 * sizeof(unsigned long long), stream));
-  hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kBuildChunk - 1u) / kBuildChunk), dim3(1024), 0, stream, bb, root_keys);
-  hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, stream, bb, root_keys);
-
-  // grow the tree one level at a time; a level is the run of nodes the previous one created
-  std::vector<std::pair<uint32_t, uint32_t>> levels;  // first id, count
-  uint32_t big_now = 0, huge_now = 0, wave_now = 0;
-  uint32_t first = 0, count = 1, big_seen = 0, huge_seen = 0, wave_seen = 0;
-  while (count != 0u) {
-    levels.push_back({first, count});
-    uint32_t tot[4] = {0, 0, 0, 0};
-    if (levels.size() == 1) {
-      BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
-      BUILD_TRY(hipStreamSynchronize(stream));
-    } else {
-      tot[1] = big_now;
-      tot[2] = huge_now;
-      tot[3] = wave_now;
-    }
-    // the shapes for big nodes only when this level holds a node of their size class
-    if (tot[2] != huge_seen) {
-      const dim3 cgrid((unsigned)max_chunks), ngrid((unsigned)((max_huge + 255) / 256));
-      hipLaunchKernelGGL(k_huge_list, dim3(1), dim3(1024), 0, stream, bb, first, count);
-      hipLaunchKernelGGL(k_huge_range, cgrid, dim3(1024), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_count, cgrid, dim3(1024), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_scan, ngrid, dim3(256), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_tables, cgrid, dim3(1024), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_place, cgrid, dim3(1024), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_copy, cgrid, dim3(1024), 0, stream, bb);
-      hipLaunchKernelGGL(k_huge_finish, ngrid, dim3(256), 0, stream, bb);
-    }
-    huge_seen = tot[2];
-    if (tot[1] != big_seen) hipLaunchKernelGGL((k_build_split<1024>), dim3(count), dim3(1024), 0, stream, bb, first);
-    big_seen = tot[1];
-    if (tot[3] != wave_seen) hipLaunchKernelGGL((k_build_split<64>), dim3(count), dim3(64), 0, stream, bb, first);
-    wave_seen = tot[3];
-    hipLaunchKernelGGL(k_build_split_tiny, dim3((count + 255u) / 256u), dim3(256), 0, stream, bb, first, count);
-    BUILD_TRY(hipMemcpyAsync(tot, bb.n_tmp, 16, hipMemcpyDeviceToHost, stream));
-    BUILD_TRY(hipStreamSynchronize(stream));
-    const uint32_t total = tot[0];
-    big_now = tot[1];
-    huge_now = tot[2];
-    wave_now = tot[3];
-    if (total > cap || total < first + count) {
-      err = "build_blas: node count out of range";
-      return MIRT_ERR_HIP;
-    }
-    first += count;
-    count = total - first;
-    if (levels.size() > (size_t)n_faces + 2) {
-      err = "build_blas: the tree is deeper than it can be";
-      return MIRT_ERR_HIP;
-    }
+  uint32_t total = 0;
+  {
+    const int rc = grow_tree(stream, bb, n_faces, cap, max_huge, max_chunks, root_keys, d_out, &total, err);
+    if (rc != MIRT_OK) return rc;
   }
-  const uint32_t total = first;
-  for (size_t l = levels.size(); l-- > 0;)
-    hipLaunchKernelGGL(k_build_up, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second);
-  for (size_t l = 0; l < levels.size(); ++l)
-    hipLaunchKernelGGL(k_build_down, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second, d_out);
   hipLaunchKernelGGL(k_build_faces, dim3(fblocks), dim3(256), 0, stream, bb);
   BUILD_TRY(hipEventRecord(ev1, stream));
   BUILD_TRY(hipGetLastError());
@@ -996,6 +1046,96 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
   }
   BUILD_TRY(hipMemcpyAsync(nodes_out, d_out, (size_t)total * sizeof(MirtBVHNode), hipMemcpyDeviceToHost, stream));
   BUILD_TRY(hipMemcpyAsync(faces4, bb.faces_out, (size_t)n_faces * 16, hipMemcpyDeviceToHost, stream));
+  BUILD_TRY(hipStreamSynchronize(stream));
+  *n_nodes = total;
+  if (device_ms) {
+    float ms = 0.0f;
+    BUILD_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    *device_ms = ms;
+  }
+  return MIRT_OK;
+}
+
+int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_geometries, const float *mats16,
+                      const uint32_t *inst_geometry, uint32_t n_instances, MirtBVHNode *nodes_out, uint32_t nodes_capacity,
+                      uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms, void **workspace, size_t *workspace_bytes,
+                      std::string &err) {
+  BuildBufs bb{};
+  const uint32_t n = n_instances;
+  bb.nf = n;
+  bb.leaf_max = kTlasLeafMax;
+  float *d_aabbs = nullptr, *d_mats = nullptr;
+  uint32_t *d_geom = nullptr;
+  MirtBVHNode *d_out = nullptr;
+  unsigned long long *root_keys = nullptr;
+  const size_t cap = 2 * (size_t)n;
+  const size_t max_huge = n / kHugeNode + 1, max_chunks = n / kBuildChunk + max_huge + 1;
+  auto carve = [&](unsigned char *base) {
+    Carver c{base};
+    c.take(&d_aabbs, 6 * (size_t)n_geometries);
+    c.take(&d_mats, 16 * (size_t)n);
+    c.take(&d_geom, n);
+    c.take(&bb.cen, n);
+    c.take(&bb.bmn, n);
+    c.take(&bb.bmx, n);
+    c.take(&bb.perm, n);
+    c.take(&bb.perm2, n);
+    c.take(&bb.rl, n);
+    c.take(&bb.lr, n);
+    c.take(&bb.pos_r, n);
+    c.take(&bb.pos_lb, n);
+    c.take(&bb.tn, cap);
+    c.take(&bb.n_tmp, 4);
+    c.take(&root_keys, 6);
+    c.take(&bb.huge, max_huge);
+    c.take(&bb.huge_hdr, 2);
+    c.take(&bb.chunk_node, max_chunks);
+    c.take(&bb.chunk_r, max_chunks);
+    c.take(&bb.chunk_lb, max_chunks);
+    c.take(&d_out, cap);
+    return c.used;
+  };
+  const size_t need = carve(nullptr);
+  if (*workspace == nullptr || *workspace_bytes < need) {
+    if (*workspace) (void)hipFree(*workspace);
+    *workspace = nullptr;
+    *workspace_bytes = 0;
+    BUILD_TRY(hipMalloc(workspace, need));
+    *workspace_bytes = need;
+  }
+  carve(static_cast<unsigned char *>(*workspace));
+  BUILD_TRY(hipMemcpyAsync(d_aabbs, geom_aabbs6, (size_t)n_geometries * 24, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemcpyAsync(d_mats, mats16, (size_t)n * 64, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemcpyAsync(d_geom, inst_geometry, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+  BUILD_TRY(hipMemsetAsync(bb.tn, 0, cap * sizeof(TNode), stream));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  BUILD_TRY(hipEventCreate(&ev0));
+  BUILD_TRY(hipEventCreate(&ev1));
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+  } guard{ev0, ev1};
+  BUILD_TRY(hipEventRecord(ev0, stream));
+  hipLaunchKernelGGL(k_tlas_prep, dim3((n + 255u) / 256u), dim3(256), 0, stream, bb, d_aabbs, d_mats, d_geom);
+  uint32_t total = 0;
+  {
+    const int rc = grow_tree(stream, bb, n, cap, max_huge, max_chunks, root_keys, d_out, &total, err);
+    if (rc != MIRT_OK) return rc;
+  }
+  BUILD_TRY(hipEventRecord(ev1, stream));
+  BUILD_TRY(hipGetLastError());
+  if (total > nodes_capacity) {
+    BUILD_TRY(hipStreamSynchronize(stream));
+    *n_nodes = total;
+    err = "build_tlas: nodes_capacity is too small (n_nodes holds the count needed)";
+    return MIRT_ERR_INVALID_ARGUMENT;
+  }
+  BUILD_TRY(hipMemcpyAsync(nodes_out, d_out, (size_t)total * sizeof(MirtBVHNode), hipMemcpyDeviceToHost, stream));
+  // instance_ids: the element at every position after the build's swaps (src/tlas.rs:36-39)
+  BUILD_TRY(hipMemcpyAsync(instance_ids, bb.perm, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
   BUILD_TRY(hipStreamSynchronize(stream));
   *n_nodes = total;
   if (device_ms) {

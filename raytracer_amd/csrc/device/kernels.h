@@ -140,6 +140,15 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
                       uint32_t n_faces, MirtBVHNode *nodes_out, uint32_t nodes_capacity, uint32_t *n_nodes,
                       float *device_ms, void **workspace, size_t *workspace_bytes, std::string &err);
 
+// TLAS::new on the device (build.hip): geom_aabbs6 = (lb3, ub3) per geometry, mats16 = the
+// column-major object-to-world matrix of every instance (built on the host with its sin / cos),
+// inst_geometry = geometry index per instance.  Fills nodes in BVHNodeGPU form and
+// instance_ids[n_instances] (the instance at every leaf slot).  Workspace as for the BLAS.
+int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_geometries, const float *mats16,
+                      const uint32_t *inst_geometry, uint32_t n_instances, MirtBVHNode *nodes_out, uint32_t nodes_capacity,
+                      uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms, void **workspace, size_t *workspace_bytes,
+                      std::string &err);
+
 // Lane-steps per second of per-lane dependent 32-byte gathers from a table of
 // `table_bytes` (diag.hip): the best of `repeats` launches of `steps` steps per
 // lane, one 1024-thread block per CU.  Allocates and frees the table.

@@ -602,12 +602,11 @@ __device__ __forceinline__ v3 material_brdf(v3 wi, v3 wo, v3 n, const DMaterial 
 // shadeMain (shaders/shade.slang:143-224) for one slot whose hit record is
 // given in registers: emission, the three sampling draws, throughput update,
 // the bounce ray.  Returns whether the path goes on.
-__device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &st, uint32_t slot, v3 wo, v3 hit_pos,
-                                                v3 hit_n, uint32_t inst, uint32_t ff, uint32_t prim, const BestHit &best,
-                                                float4 &rad_out, uint32_t &source_out) {
-  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
-  float4 pa = p4[0], pb = p4[1];
-  const float4 pr = p4[2];
+// The slot's path record comes in and goes out in registers (pa: radiance +
+// bounces, pb: throughput + source, pr: stream state); the caller stores it, and
+// the bounce ray wi from the hit point, only when the path goes on.
+__device__ __forceinline__ bool shade_uber_slot(const DScene &sc, v3 wo, v3 hit_n, uint32_t inst, uint32_t ff,
+                                                const BestHit &best, float4 &pa, float4 &pb, float4 &pr, v3 &wi_out) {
   Rng rng{__float_as_uint(pr.x), __float_as_uint(pr.y), __float_as_uint(pr.z), __float_as_uint(pr.w)};
   DMaterial mat = sc.mat[sc.inst[inst].material];
   if ((mat.tex[0] | mat.tex[1]) != 0u) {
@@ -642,14 +641,8 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, const DState &
   pb.z = pb.z * (brdf.z * ndotwi * 1.0f / pdf);
   const uint32_t bounces = __float_as_uint(pa.w) - 1u;
   pa.w = __uint_as_float(bounces);
-  rad_out = pa;
-  source_out = __float_as_uint(pb.w);
-  p4[0] = pa;
-  p4[1] = pb;
-  p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
-  // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just
-  // hit is excluded from the next traversal instead
-  store_ray(st.ray, slot, hit_pos, wi, inst, prim);
+  pr = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+  wi_out = wi;
   return bounces != 0u;
 }
 
@@ -678,45 +671,59 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade
   CamBasis cb;
   if (RESPAWN) cb = cam_basis(fp.cam);
   unsigned long long shaded = 0, finished = 0, spawned = 0;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {  // uniform per block
+  // Every access of this kernel is a miss of its own (slots are scattered over gigabytes of
+  // path state), so what it waits for is round trips, not bytes: everything addressed by the
+  // slot alone — the traversal's result, the path record, the ray — is requested at once, before
+  // any of it is looked at, and the next round's queue entry is requested a round ahead.
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t next_slot = 0;
+  if (blockIdx.x * blockDim.x + threadIdx.x < count) next_slot = ext[blockIdx.x * blockDim.x + threadIdx.x];
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
-    uint32_t slot = 0;
+    const uint32_t slot = next_slot;
+    if (i + stride < count) next_slot = ext[i + stride];
     bool alive = false;
     float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // of a path that ends here
     uint32_t source = kNoSample;
     if (active) {
-      slot = ext[i];
-      const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
-      const float4 raw = h4[0];
+      float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
+      const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
+      const float4 raw = reinterpret_cast<const float4 *>(st.hit + slot)[0];
+      float4 pa = p4[0], pb = p4[1], pr = p4[2];
+      const float4 ra = r4[0], rb = r4[1];
       BestHit best;
       best.u = raw.x;
       best.v = raw.y;
       best.t = 0.0f;
       best.prim = __float_as_uint(raw.z);
       best.inst = __float_as_uint(raw.w);
+      source = __float_as_uint(pb.w);
       if (best.inst == kMissInst) {
         // rad += throughput * sky
-        float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
-        float4 a = p4[0];
-        const float4 b = p4[1];
         const float sky = fp.p.sky_radiance;
-        a.x = a.x + b.x * sky;
-        a.y = a.y + b.y * sky;
-        a.z = a.z + b.z * sky;
-        if (RESPAWN) {
-          rad = a;
-          source = __float_as_uint(b.w);
-        } else {
-          p4[0] = a;
-        }
+        pa.x = pa.x + pb.x * sky;
+        pa.y = pa.y + pb.y * sky;
+        pa.z = pa.z + pb.z * sky;
+        rad = pa;
+        if (!RESPAWN) p4[0] = pa;
       } else {
-        v3 rpos, wo, hp, hn;
-        uint32_t li, lp, ff;
-        load_ray(st.ray, slot, rpos, wo, li, lp);  // wo = incoming direction, not negated
+        const v3 wo = V3(ra.w, rb.x, rb.y);  // the incoming direction, not negated
+        v3 hp, hn, wi;
+        uint32_t ff;
         finish_hit(sc, wo, best, hp, hn, ff);
-        alive = shade_uber_slot(sc, st, slot, wo, hp, hn, best.inst, ff, best.prim, best, rad, source);
+        alive = shade_uber_slot(sc, wo, hn, best.inst, ff, best, pa, pb, pr, wi);
+        rad = pa;
         shaded++;
+        if (alive || !RESPAWN) {
+          // (with RESPAWN a path that ends here is overwritten by its slot's next sample at once)
+          p4[0] = pa;
+          p4[1] = pb;
+          p4[2] = pr;
+        }
+        // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just hit is excluded
+        // from the next traversal instead
+        if (alive) store_ray(st.ray, slot, hp, wi, best.inst, best.prim);
       }
     }
     if (RESPAWN) {

@@ -234,7 +234,7 @@ DEVICE_SYMBOLS = [
     "mirt_read_accum", "mirt_copy_accum_to_device", "mirt_load_accum_from_device",
     "mirt_trace_closest", "mirt_trace_closest_static", "mirt_trace_any", "mirt_bench_trace_closest", "mirt_bench_gather", "mirt_scene_bytes", "mirt_stats",
     "mirt_stats_reset", "mirt_set_counting", "mirt_set_event_timing", "mirt_dump_extension_rays",
-    "mirt_math_selftest", "mirt_build_blas",
+    "mirt_math_selftest", "mirt_build_blas", "mirt_build_tlas",
     "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_member", "mirt_group_last_error",
     "mirt_group_scene_upload", "mirt_group_scene_update_instances", "mirt_group_state_create",
     "mirt_group_camera_set", "mirt_group_reset_accum", "mirt_group_render_spp", "mirt_group_reduce",
@@ -288,6 +288,7 @@ def device_lib():
         L.mirt_dump_extension_rays.argtypes = [vp, vp, sz, C.POINTER(sz)]
         L.mirt_math_selftest.argtypes = [vp, vp, vp, vp, sz, vp]
         L.mirt_build_blas.argtypes = [vp, vp, u32, vp, u32, vp, u32, C.POINTER(u32), C.POINTER(C.c_float)]
+        L.mirt_build_tlas.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, u32, C.POINTER(u32), vp, C.POINTER(C.c_float)]
         L.mirt_group_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
         L.mirt_group_destroy.argtypes = [vp]
         L.mirt_group_size.argtypes = [vp]

@@ -185,6 +185,19 @@ class Pathtracer:
                                             nodes.ctypes.data, len(nodes), C.byref(n), C.byref(ms)), "mirt_build_blas")
         return faces, nodes[:n.value].copy(), ms.value
 
+    def build_tlas(self, geom_aabbs6, transforms, instances):
+        """TLAS::new on the device: (nodes[k], instance_ids[n], device ms)."""
+        a = np.ascontiguousarray(geom_aabbs6, "<f4").reshape(-1, 6)
+        t = np.ascontiguousarray(transforms, ffi.Transform)
+        inst = np.ascontiguousarray(instances, ffi.Instance)
+        nodes = np.zeros(max(2 * len(inst), 1), ffi.BVHNode)
+        ids = np.zeros(len(inst), "<u4")
+        n, ms = C.c_uint32(), C.c_float()
+        self._check(self._L.mirt_build_tlas(self._h, a.ctypes.data, len(a), t.ctypes.data, len(t), inst.ctypes.data,
+                                            len(inst), nodes.ctypes.data, len(nodes), C.byref(n), ids.ctypes.data,
+                                            C.byref(ms)), "mirt_build_tlas")
+        return nodes[:n.value].copy(), ids, ms.value
+
     def blas_builder_callback(self):
         """(function pointer, user pointer) for Scene.set_blas_builder: mirt_build_blas on this context."""
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,

@@ -142,6 +142,12 @@ extern "C" {
     pub fn mirt_build_blas(ctx: *mut mirt_ctx, positions4: *const f32, n_positions: u32, faces4: *mut u32,
                            n_faces: u32, nodes: *mut crate::bvh::BVHNodeGPU, nodes_capacity: u32,
                            n_nodes: *mut u32, device_ms: *mut f32) -> c_int;
+    // TLAS::new on the device
+    pub fn mirt_build_tlas(ctx: *mut mirt_ctx, geom_aabbs6: *const f32, n_geometries: u32,
+                           transforms: *const crate::transform::Transform, n_transforms: u32,
+                           instances: *const crate::instance::Instance, n_instances: u32,
+                           nodes: *mut crate::bvh::BVHNodeGPU, nodes_capacity: u32, n_nodes: *mut u32,
+                           instance_ids: *mut u32, device_ms: *mut f32) -> c_int;
     // several GPUs from this one process
     pub fn mirt_group_create(device_ordinals: *const c_int, n: c_int, out_group: *mut *mut mirt_group) -> c_int;
     pub fn mirt_group_destroy(grp: *mut mirt_group) -> c_int;

@@ -179,3 +179,60 @@ def test_bad_arguments_are_refused(pt):
     assert rc != 0 and n.value == len(want_nodes) and np.array_equal(f1, f0)  # the faces were left alone
     faces, nodes, _ = pt.build_blas(p4, f0)
     assert np.array_equal(faces, want_faces) and nodes.tobytes() == want_nodes.tobytes()
+
+
+# ------------------------------------------------------------------ TLAS
+
+def assert_same_tlas(pt, name, arrays):
+    """mirt_build_tlas against the host model's TLAS::new (src/tlas.rs:61-158) for the same
+    geometry boxes, transforms and instances: node array and instance ids byte for byte."""
+    roots = arrays["blas_nodes"][arrays["geometry_offsets"]["blas_node"]]
+    aabbs = np.concatenate([roots["lb"][:, :3], roots["ub"][:, :3]], axis=1)
+    nodes, ids, ms = pt.build_tlas(aabbs, arrays["transforms"], arrays["instances"])
+    assert np.array_equal(ids, arrays["tlas_to_instances"]), name
+    assert len(nodes) == len(arrays["tlas_nodes"]), (name, len(nodes), len(arrays["tlas_nodes"]))
+    assert nodes.tobytes() == arrays["tlas_nodes"].tobytes(), name
+    return ms
+
+
+def scattered_scene(n, seed):
+    rng = np.random.default_rng(seed)
+    s = host.Scene()
+    meshes = [s.load_cube(), s.load_rect()]
+    mat = s.add_material(host.make_material())
+    for i in range(n):
+        # clusters, coincident instances and degenerate scales next to ordinary ones
+        centre = rng.integers(0, 7, 3) * 10.0 if i % 3 else np.zeros(3)
+        t = host.make_transform(scale=rng.uniform(0.2, 3.0, 3) if i % 17 else (1.0, 0.0, 1.0),
+                                rotation=rng.uniform(-4.0, 4.0, 3), translation=centre + rng.normal(0, 2.0, 3) * (i % 5 != 0))
+        s.spawn(t, mat, meshes[i % 2])
+    arrays = s.bind()
+    s.close()
+    return arrays
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 16, 17, 65, 1000, 20001])
+def test_tlas_of_scattered_instances(pt, n):
+    # sizes around one-thread nodes (16), one wave (64) and nodes split by many blocks (16384)
+    assert_same_tlas(pt, f"scattered{n}", scattered_scene(n, n))
+
+
+def test_tlas_of_the_benchmark_scenes(pt, config_scenes):
+    for cfg, kw in ((1, {}), (2, {}), (3, dict(dragon_n_u=48, dragon_n_v=12)), (4, dict(dragon_n_u=48, dragon_n_v=12))):
+        arrays, _ = config_scenes(cfg, **kw)
+        assert_same_tlas(pt, f"config{cfg}", arrays)
+    # moved instances: rebuild on the device, upload, trace — same hits as the host-built scene
+    arrays, _ = config_scenes(4, dragon_n_u=48, dragon_n_v=12)
+    moved = {k: v.copy() for k, v in arrays.items()}
+    rng = np.random.default_rng(5)
+    moved["transforms"]["translation"][:, :3] += rng.normal(0, 0.3, (len(moved["transforms"]), 3)).astype("<f4")
+    roots = moved["blas_nodes"][moved["geometry_offsets"]["blas_node"]]
+    aabbs = np.concatenate([roots["lb"][:, :3], roots["ub"][:, :3]], axis=1)
+    nodes, ids, _ = pt.build_tlas(aabbs, moved["transforms"], moved["instances"])
+    moved["tlas_nodes"], moved["tlas_to_instances"] = nodes, ids
+    pt.upload_scene(arrays)
+    pt.update_instances(moved)
+    from conftest import hits_equal, random_rays
+    from oracle import pyoracle as po
+    rays = random_rays(50000, 4, centre=(0.0, 0.0, 14.0), spread=10.0)
+    assert hits_equal(pt.trace_closest(rays), po.Scene(moved).trace_closest(rays))
