@@ -70,7 +70,6 @@ struct mirt_ctx {
   // scene
   bool have_scene = false;
   bool have_classic_tables = false;  // the scene came with classic_refs (per-material shading can run)
-  bool textured_light = false;       // a listed light's material has an emissive texture
   DScene sc{};
   std::vector<void *> scene_allocs;     // geometry: nodes + triangles, normals
   std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
@@ -833,12 +832,6 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       if ((rc = dev_upload(ctx, own, &sc.texels, texels)) != MIRT_OK) return rc;
       sc.n_textures = d->n_textures;
     }
-    // light sampling reads a light's emission from its per-material row, not through a texture
-    ctx->textured_light = false;
-    for (uint32_t i = 0; i < d->n_light_sources; ++i) {
-      const uint32_t li = d->light_sources[i];
-      if (li != 0xFFFFFFFFu && d->materials[d->instances[li].material].emissive_texture != 0u) ctx->textured_light = true;
-    }
     if ((rc = dev_upload(ctx, own, &sc.mat, mats)) != MIRT_OK) return rc;
     const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
     std::vector<uint32_t> lights;
@@ -1104,10 +1097,6 @@ static int check_ready(mirt_ctx *ctx) {
   if (!ctx->have_camera) return fail(ctx, MIRT_ERR_NOT_READY, "no camera set");
   if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && !ctx->have_classic_tables)
     return fail(ctx, MIRT_ERR_NOT_READY, "classic shading needs the per-material tables");
-  if (ctx->params.shade_mode == MIRT_SHADE_CLASSIC && ctx->params.nee && ctx->textured_light)
-    return fail(ctx, MIRT_ERR_NOT_READY,
-                "light sampling (nee) does not read emissive textures: a listed light has one; render with nee = 0 "
-                "or uber shading");
   if (ctx->params.rng_mode == MIRT_RNG_PER_SLOT && !ctx->rng_seeded)
     return fail(ctx, MIRT_ERR_NOT_READY, "per-slot random streams need mirt_state_set_rng");
   return MIRT_OK;

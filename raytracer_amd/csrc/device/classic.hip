@@ -149,6 +149,13 @@ __global__ __launch_bounds__(kEngineBlock) void k_connect(DScene sc, DState st, 
       b = 1.0f - b;
     }
     store_rng(st.path + slot, rng);
+    if (sc.tri_uv != nullptr) {
+      // scenes with textures: where on which light triangle the sample lies rides to k_connect_finish
+      // in the ray record's origin, which nothing reads between the traversal and the material kernel
+      reinterpret_cast<float *>(st.ray + slot)[0] = a;
+      reinterpret_cast<float *>(st.ray + slot)[1] = b;
+      reinterpret_cast<uint32_t *>(st.ray + slot)[2] = light_prim;
+    }
     const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
     const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
     const float area = 0.5f * length3(cr);
@@ -212,6 +219,20 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
         if (linst->kind == MIRT_MAT_EMISSIVE) {
           const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
           s1 = make_float4(e[0], e[1], e[2], 0.0f);
+          const uint32_t tex = sc.tri_uv != nullptr ? sc.mat[linst->material].tex[1] : 0u;
+          if (tex != 0u) {
+            // an emissive texture on the light: the texel at the sampled point
+            BestHit lb;
+            lb.t = 0.0f;
+            lb.u = reinterpret_cast<const float *>(st.ray + slot)[0];
+            lb.v = reinterpret_cast<const float *>(st.ray + slot)[1];
+            lb.prim = reinterpret_cast<const uint32_t *>(st.ray + slot)[2];
+            lb.inst = light_inst;
+            float tu, tv;
+            hit_uv(sc, lb, tu, tv);
+            const v3 c = tex_sample(sc, tex, tu, tv);
+            s1 = make_float4(s1.x * c.x, s1.y * c.y, s1.z * c.z, 0.0f);
+          }
         }
       } else {
         s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -135,18 +135,14 @@ def test_textured_scene_matches_the_oracle_in_both_shading_paths():
             s4, cnt = pt.read_accum()
             w4, wcnt, _ = sc.step_wavefront(cam, src, W, H, po.default_params(**kw), 0, 9, 2500)
             assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4)
-        # light sampling: a textured emitter on the light list is refused, an untextured one next to
-        # textured surfaces renders like the oracle
-        pt.create_state(W, H, 2500, src, pathtracer.default_params(max_bounces=5, seed=21, shade_mode=1, nee=1))
-        pt.set_camera(cam)
-        with pytest.raises(pathtracer.MirtError, match="emissive textures"):
-            pt.render_spp(1)
+        # light sampling: the textured emitter is on the light list (its texel is looked up at the sampled
+        # point), next to an untextured one added through the instance-update call
         glow_inst = int(arrays["light_sources"][0])
         s.spawn(host.make_transform(scale=(1, 1, 1), rotation=(np.pi / 2, 0, 0), translation=(0, 1.8, 3.0)), plain_light, rect)
         lit = s.bind()
         s.close()
-        lit["materials"]["emissive_texture"] = 0  # the glowing panel keeps its factor, loses its texture
         assert len(lit["light_sources"]) == 2 and glow_inst in lit["light_sources"].tolist()
+        assert lit["materials"]["emissive_texture"].max() == 3
         pt.update_instances(lit)  # textures and materials are instance-side data: no geometry upload
         kw = dict(max_bounces=5, seed=21, shade_mode=1, nee=1)
         pt.create_state(W, H, 2500, src, pathtracer.default_params(**kw))
@@ -157,9 +153,14 @@ def test_textured_scene_matches_the_oracle_in_both_shading_paths():
         w4, wcnt, wst = po.Scene(lit).render(cam, src, W, H, po.default_params(**kw), 0, 2)
         assert wst.connect_rays > 1000 and pt.stats().connect_rays == wst.connect_rays
         assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4)
+        untextured = {k: v.copy() for k, v in lit.items()}
+        untextured["materials"]["emissive_texture"] = 0
+        u4, _, _ = po.Scene(untextured).render(cam, src, W, H, po.default_params(**kw), 0, 2)
+        assert not np.array_equal(u4, w4)  # the light's texture is seen by the connect stage
         # a scene first uploaded without textures gets them through the update call (falls back to a full upload)
         bare = {k: v.copy() for k, v in lit.items() if k not in ("textures", "texels")}
         bare["materials"]["colour_texture"] = 0
+        bare["materials"]["emissive_texture"] = 0
         pt.upload_scene(bare)
         pt.update_instances(lit)
         pt.create_state(W, H, 2500, src, pathtracer.default_params(**kw))
