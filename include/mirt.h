@@ -314,6 +314,19 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *scene);
  * outgrew the room reserved for it. */
 int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *scene);
 
+/* The same regeneration when ONLY transforms moved (binder_system's
+ * transform.is_changed() case, src/binder.rs:199-206): instances, materials,
+ * lights and geometry are those of the last upload, `transforms` replaces its
+ * transforms array (same count).  Nothing but the instance matrices (formed on
+ * the host) crosses PCIe: instance boxes, TLAS::new (src/tlas.rs:61-158) and its
+ * packing into the traversal layout run on the device, over the old TLAS in
+ * place.  device_ms (may be NULL) receives the device time of build + packing.
+ * The result is what mirt_scene_update_instances gives for the host-built TLAS
+ * of the same transforms.  Fails (nothing changed) when the new TLAS has more
+ * nodes than the room reserved at upload: 1.5 x the uploaded TLAS + 16. */
+int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
+                                 uint32_t n_transforms, float *device_ms);
+
 /* Replaces PathtracerState::new (src/pathtracer_state.rs:96-353) and
  * PathtracerOutput::new (src/pathtracer.rs:56-122): allocates `threads` path
  * slots, the four queues, the accumulators for `n_sources` sample sources and

@@ -76,6 +76,11 @@ struct mirt_ctx {
   uint32_t n_instances = 0, n_geometries = 0;
   uint32_t tlas_capacity = 0;  // nodes reserved for the TLAS at the front of the node array
   std::vector<uint32_t> geom_node_base, geom_tri_base, geom_root_start, geom_root_count;
+  // kept for mirt_scene_update_transforms: each geometry's root box, the instances and their device records
+  std::vector<float> geom_aabbs6;
+  std::vector<MirtInstance> host_instances;
+  std::vector<DInst> host_insts;
+  uint32_t n_transforms = 0;
 
   // state
   bool have_state = false;
@@ -574,6 +579,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   ctx->geom_tri_base.assign(d->n_geometries, 0);
   ctx->geom_root_start.assign(d->n_geometries, 0);
   ctx->geom_root_count.assign(d->n_geometries, 0);
+  ctx->geom_aabbs6.clear();
   // Host staging is written exactly once: the big arrays are left uninitialised
   // (value-initialising 150 MB costs more than packing it) and the triangles are
   // packed straight into the geometry buffer once its layout is known.
@@ -607,6 +613,8 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     // triangle of its geometry — which is what the reference's builder leaves
     // in them (src/bvh.rs:144-151); a leaf root's range has been validated.
     const MirtBVHNode &root = d->blas_nodes[o.blas_node];
+    ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.lb, root.lb + 3);
+    ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.ub, root.ub + 3);
     const uint32_t idx_end_g = last ? d->n_indices : d->geometry_offsets[g + 1].index;
     ctx->geom_root_start[g] = root.is_leaf == 1 ? root.start : 0u;
     ctx->geom_root_count[g] = root.is_leaf == 1 ? root.end - root.start : idx_end_g - o.index;
@@ -806,6 +814,9 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       insts[i] = di;
     }
     if ((rc = dev_upload(ctx, own, &sc.inst, insts)) != MIRT_OK) return rc;
+    ctx->host_insts = insts;
+    ctx->host_instances.assign(d->instances, d->instances + d->n_instances);
+    ctx->n_transforms = d->n_transforms;
   }
   {
     std::vector<DMaterial> mats(d->n_materials);
@@ -895,6 +906,51 @@ int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
   ctx->n_instances = d->n_instances;
   ctx->have_classic_tables = d->n_classic_refs != 0;
   ctx->have_scene = true;
+  return MIRT_OK;
+}
+
+int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) {
+  ENTER(ctx);
+  if (device_ms) *device_ms = 0.0f;
+  if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
+  if (!transforms || n_transforms != ctx->n_transforms)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "update_transforms: as many transforms as the scene was uploaded with");
+  const uint32_t n = ctx->n_instances;
+  // instance matrices on the host (its sin / cos), as in a full upload
+  std::vector<DInst> insts = ctx->host_insts;
+  std::vector<float> mats((size_t)16 * n);
+  std::vector<uint32_t> geom(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    DInst &di = insts[i];
+    instance_matrices(transforms[ctx->host_instances[i].transform], di.m, di.mi);
+    float *c = &mats[(size_t)16 * i];
+    for (int col = 0; col < 4; ++col)
+      for (int r = 0; r < 3; ++r) c[4 * col + r] = di.m[4 * r + col];
+    c[3] = c[7] = c[11] = 0.0f;
+    c[15] = 1.0f;
+    geom[i] = ctx->host_instances[i].geometry;
+  }
+  // boxes, tree and the traversal-layout TLAS on the device, written over the old one in place (stream order
+  // keeps frames already submitted on the old TLAS); nothing of the scene is touched when the new tree does
+  // not fit the room reserved for it
+  TlasResident res;
+  res.nodes = const_cast<DNode *>(ctx->sc.nodes) + ctx->sc.tlas_base;
+  res.capacity = ctx->tlas_capacity;
+  res.big = const_cast<uint32_t *>(ctx->sc.tlas_big);
+  res.to_inst = const_cast<uint32_t *>(ctx->sc.tlas_to_inst);
+  uint32_t n_nodes = 0;
+  std::string err;
+  const int rc = build_tlas_device(ctx->stream, ctx->geom_aabbs6.data(), ctx->n_geometries, mats.data(), geom.data(), n,
+                                   nullptr, 0, &n_nodes, nullptr, device_ms, &ctx->build_ws, &ctx->build_ws_bytes, err, &res);
+  if (rc != MIRT_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return fail(ctx, rc, err);
+  }
+  // the instance records with their new matrices, in one copy behind the tree
+  HIP_TRY(ctx, hipMemcpyAsync(const_cast<DInst *>(ctx->sc.inst), insts.data(), (size_t)n * sizeof(DInst),
+                              hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffers of the copies above must outlive them
+  ctx->host_insts.swap(insts);
   return MIRT_OK;
 }
 

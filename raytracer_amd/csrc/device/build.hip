@@ -872,6 +872,30 @@ __global__ __launch_bounds__(256) void k_build_faces(BuildBufs bb) {
   if (p < bb.nf) bb.faces_out[p] = bb.faces[bb.perm[p]];
 }
 
+// The TLAS as the traversal kernels read it, written where it lives (layout.h: 32-byte nodes,
+// every leaf tagged "size out of line" so that the walk hands it to its service point, the size at
+// tlas_big[first slot], the instance of every slot in tlas_to_inst) — from the builder's output on
+// the device, without a trip through the host.
+__global__ __launch_bounds__(256) void k_pack_tlas(const MirtBVHNode *src, uint32_t n_nodes, const uint32_t *perm,
+                                                   uint32_t n_slots, DNode *dst, uint32_t *tlas_big, uint32_t *tlas_to_inst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n_slots) tlas_to_inst[i] = perm[i];
+  if (i >= n_nodes) return;
+  const MirtBVHNode s = src[i];
+  DNode d;
+  d.lbx = s.lb[0]; d.lby = s.lb[1]; d.lbz = s.lb[2];
+  d.ubx = s.ub[0]; d.uby = s.ub[1]; d.ubz = s.ub[2];
+  if (s.is_leaf == 1u) {
+    d.a = s.start;
+    d.b = (s.right & kSkipMask) | (kBigLeaf << 24);
+    tlas_big[s.start] = s.end - s.start;
+  } else {
+    d.a = s.left;
+    d.b = s.right & kSkipMask;
+  }
+  dst[i] = d;
+}
+
 // Carves 256-byte aligned arrays out of one workspace allocation.
 struct Carver {
   unsigned char *base;
@@ -1059,7 +1083,7 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
 int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_geometries, const float *mats16,
                       const uint32_t *inst_geometry, uint32_t n_instances, MirtBVHNode *nodes_out, uint32_t nodes_capacity,
                       uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms, void **workspace, size_t *workspace_bytes,
-                      std::string &err) {
+                      std::string &err, const TlasResident *resident) {
   BuildBufs bb{};
   const uint32_t n = n_instances;
   bb.nf = n;
@@ -1124,6 +1148,26 @@ int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_g
   {
     const int rc = grow_tree(stream, bb, n, cap, max_huge, max_chunks, root_keys, d_out, &total, err);
     if (rc != MIRT_OK) return rc;
+  }
+  if (resident != nullptr) {
+    // stay on the device: pack straight into the scene's TLAS block
+    *n_nodes = total;
+    if (total > resident->capacity) {
+      err = "update_transforms: the TLAS outgrew the room reserved for it";
+      return MIRT_ERR_INVALID_ARGUMENT;
+    }
+    const uint32_t work = total > n ? total : n;
+    hipLaunchKernelGGL(k_pack_tlas, dim3((work + 255u) / 256u), dim3(256), 0, stream, d_out, total, bb.perm, n,
+                       resident->nodes, resident->big, resident->to_inst);
+    BUILD_TRY(hipEventRecord(ev1, stream));
+    BUILD_TRY(hipGetLastError());
+    if (device_ms) {
+      BUILD_TRY(hipStreamSynchronize(stream));
+      float ms = 0.0f;
+      BUILD_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+      *device_ms = ms;
+    }
+    return MIRT_OK;
   }
   BUILD_TRY(hipEventRecord(ev1, stream));
   BUILD_TRY(hipGetLastError());

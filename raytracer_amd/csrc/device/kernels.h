@@ -144,10 +144,18 @@ int build_blas_device(hipStream_t stream, const float *positions4, uint32_t n_po
 // column-major object-to-world matrix of every instance (built on the host with its sin / cos),
 // inst_geometry = geometry index per instance.  Fills nodes in BVHNodeGPU form and
 // instance_ids[n_instances] (the instance at every leaf slot).  Workspace as for the BLAS.
+// With `resident` the result stays on the device: it is packed into the scene's own TLAS block
+// (traversal layout) and nodes_out / instance_ids are not written.
+struct TlasResident {
+  DNode *nodes;        // the scene's TLAS block
+  uint32_t capacity;   // nodes it has room for
+  uint32_t *big;       // out-of-line leaf sizes, indexed by the leaf's first slot
+  uint32_t *to_inst;   // instance of every slot
+};
 int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_geometries, const float *mats16,
                       const uint32_t *inst_geometry, uint32_t n_instances, MirtBVHNode *nodes_out, uint32_t nodes_capacity,
                       uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms, void **workspace, size_t *workspace_bytes,
-                      std::string &err);
+                      std::string &err, const TlasResident *resident = nullptr);
 
 // Lane-steps per second of per-lane dependent 32-byte gathers from a table of
 // `table_bytes` (diag.hip): the best of `repeats` launches of `steps` steps per

@@ -228,7 +228,7 @@ def host_lib():
 
 DEVICE_SYMBOLS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_status_string", "mirt_default_params",
-    "mirt_scene_upload", "mirt_scene_update_instances", "mirt_state_create", "mirt_camera_set", "mirt_reset_accum",
+    "mirt_scene_upload", "mirt_scene_update_instances", "mirt_scene_update_transforms", "mirt_state_create", "mirt_camera_set", "mirt_reset_accum",
     "mirt_set_sample_range", "mirt_state_set_rng", "mirt_adapt_update", "mirt_read_flags", "mirt_read_moments",
     "mirt_write_moments", "mirt_step", "mirt_render_spp", "mirt_synchronize", "mirt_read_output",
     "mirt_read_accum", "mirt_copy_accum_to_device", "mirt_load_accum_from_device",
@@ -259,6 +259,7 @@ def device_lib():
         L.mirt_default_params.argtypes = [C.POINTER(Params)]
         L.mirt_scene_upload.argtypes = [vp, C.POINTER(SceneDesc)]
         L.mirt_scene_update_instances.argtypes = [vp, C.POINTER(SceneDesc)]
+        L.mirt_scene_update_transforms.argtypes = [vp, vp, u32, C.POINTER(C.c_float)]
         L.mirt_state_create.argtypes = [vp, u32, u32, u32, vp, u32, C.POINTER(Params)]
         L.mirt_camera_set.argtypes = [vp, vp]
         L.mirt_reset_accum.argtypes = [vp]

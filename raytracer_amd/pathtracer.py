@@ -73,6 +73,14 @@ class Pathtracer:
         d = ffi.desc_from_arrays(arrays)
         self._check(self._L.mirt_scene_update_instances(self._h, C.byref(d)), "mirt_scene_update_instances")
 
+    def update_transforms(self, transforms):
+        """Only transforms moved: instance boxes, TLAS build and packing on the device.  Returns device ms."""
+        t = np.ascontiguousarray(transforms, ffi.Transform)
+        ms = C.c_float()
+        self._check(self._L.mirt_scene_update_transforms(self._h, t.ctypes.data, len(t), C.byref(ms)),
+                    "mirt_scene_update_transforms")
+        return ms.value
+
     def create_state(self, width, height, threads, sources, params):
         sources = np.ascontiguousarray(sources, ffi.SampleSource)
         self._check(self._L.mirt_state_create(self._h, width, height, threads, sources.ctypes.data, len(sources),

@@ -103,6 +103,8 @@ extern "C" {
     // scene and state
     pub fn mirt_scene_upload(ctx: *mut mirt_ctx, scene: *const MirtSceneDesc) -> c_int;
     pub fn mirt_scene_update_instances(ctx: *mut mirt_ctx, scene: *const MirtSceneDesc) -> c_int;
+    pub fn mirt_scene_update_transforms(ctx: *mut mirt_ctx, transforms: *const crate::transform::Transform,
+                                        n_transforms: u32, device_ms: *mut f32) -> c_int;
     pub fn mirt_state_create(ctx: *mut mirt_ctx, width: u32, height: u32, threads: u32,
                              sources: *const crate::pathtracer_state::SampleSource, n_sources: u32,
                              params: *const MirtParams) -> c_int;

@@ -236,3 +236,52 @@ def test_tlas_of_the_benchmark_scenes(pt, config_scenes):
     from oracle import pyoracle as po
     rays = random_rays(50000, 4, centre=(0.0, 0.0, 14.0), spread=10.0)
     assert hits_equal(pt.trace_closest(rays), po.Scene(moved).trace_closest(rays))
+
+
+def test_transforms_only_update_stays_on_the_device(pt, config_scenes):
+    """mirt_scene_update_transforms: new matrices, instance boxes, TLAS and its traversal layout without the
+    host builder — the same hits as the host-bound moved scene through the oracle, frame after frame."""
+    from conftest import hits_equal, random_rays
+    from oracle import pyoracle as po
+    arrays, _ = config_scenes(4, dragon_n_u=48, dragon_n_v=12)
+    pt.upload_scene(arrays)
+    rays = random_rays(50000, 4, centre=(0.0, 0.0, 14.0), spread=10.0)
+    rng = np.random.default_rng(6)
+    moved = {k: v.copy() for k, v in arrays.items()}
+    for step in range(3):
+        moved["transforms"]["translation"][:, :3] += rng.normal(0, 0.3, (len(moved["transforms"]), 3)).astype("<f4")
+        moved["transforms"]["rotation"][:, :3] += rng.normal(0, 0.2, (len(moved["transforms"]), 3)).astype("<f4")
+        ms = pt.update_transforms(moved["transforms"])
+        assert ms > 0.0
+        # what the host would have bound for these transforms (TLAS::new on the device is byte-identical to it)
+        roots = moved["blas_nodes"][moved["geometry_offsets"]["blas_node"]]
+        aabbs = np.concatenate([roots["lb"][:, :3], roots["ub"][:, :3]], axis=1)
+        moved["tlas_nodes"], moved["tlas_to_instances"], _ = pt.build_tlas(aabbs, moved["transforms"], moved["instances"])
+        want = po.Scene(moved).trace_closest(rays)
+        assert hits_equal(pt.trace_closest(rays), want), step
+    # and the same hits as the upload path for the same scene
+    pt.update_instances(moved)
+    assert hits_equal(pt.trace_closest(rays), want)
+    with pytest.raises(pathtracer.MirtError):
+        pt.update_transforms(moved["transforms"][:-1])
+
+
+def test_transforms_only_update_refuses_a_tree_that_outgrew_its_room(pt):
+    # ten coincident instances bind to a single leaf, so little room is reserved; moved apart they need 19 nodes
+    s = host.Scene()
+    cube = s.load_cube()
+    mat = s.add_material(host.make_material())
+    for _ in range(40):
+        s.spawn(host.make_transform(), mat, cube)
+    arrays = s.bind()
+    s.close()
+    assert len(arrays["tlas_nodes"]) == 1
+    from conftest import hits_equal, random_rays
+    rays = random_rays(2000, 9, centre=(0.0, 0.0, 0.0), spread=3.0)
+    pt.upload_scene(arrays)
+    before = pt.trace_closest(rays)
+    apart = arrays["transforms"].copy()
+    apart["translation"][:, 0] = np.arange(len(apart), dtype="<f4") * 5.0
+    with pytest.raises(pathtracer.MirtError, match="outgrew"):
+        pt.update_transforms(apart)
+    assert hits_equal(pt.trace_closest(rays), before)   # the scene was left as it was
