@@ -53,3 +53,15 @@ pub fn upload_scene(
     };
     ffi::check(ctx.0, rc, "mirt_scene_upload");
 }
+
+/// Only `Transform`s changed since the last upload (the `Changed<Transform>` arm that sets
+/// `tlas_regenerate`, src/binder.rs:257-282, with the same instances and materials as before):
+/// the TLAS is rebuilt and written in place on the device, `TLAS::new` is not run on the host.
+/// Returns false when the new tree does not fit the block reserved at upload; the caller then
+/// rebuilds on the host and calls `upload_scene(.., geometry_changed = false)`.
+pub fn move_transforms(ctx: &MirtContext, transforms: &[crate::transform::Transform]) -> bool {
+    let rc = unsafe {
+        ffi::mirt_scene_update_transforms(ctx.0, transforms.as_ptr(), transforms.len() as u32, std::ptr::null_mut())
+    };
+    rc == ffi::MIRT_OK
+}
