@@ -75,6 +75,10 @@ struct mirt_ctx {
   std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
   uint32_t n_instances = 0, n_geometries = 0;
   uint32_t tlas_capacity = 0;  // nodes reserved for the TLAS at the front of the node array
+  // the walk's stack: tallest BLAS, the TLAS height the spill rows allow for, the rows themselves
+  uint32_t blas_height = 0, tlas_height_room = 0;
+  unsigned char *stack_spill = nullptr;
+  size_t stack_spill_bytes = 0;
   std::vector<uint32_t> geom_node_base, geom_tri_base, geom_root_start, geom_root_count;
   // kept for mirt_scene_update_transforms: each geometry's root box, the instances and their device records
   std::vector<float> geom_aabbs6;
@@ -125,6 +129,14 @@ int fail(mirt_ctx *c, int status, const std::string &msg) {
                   std::string(#expr) + ": " + hipGetErrorString(_e));                           \
   } while (0)
 
+// Every copy and fill of the context's memory goes through its stream: the stream is
+// non-blocking, so work on the null stream (hipMemcpy, hipMemset) is not ordered with its
+// kernels.  Complete on return, so the host side may be a temporary.
+hipError_t copy_sync(hipStream_t stream, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, stream);
+  return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+}
+
 template <typename T>
 int dev_alloc(mirt_ctx *c, std::vector<void *> &owner, T **out, size_t count) {
   void *p = nullptr;
@@ -141,7 +153,7 @@ int dev_upload(mirt_ctx *c, std::vector<void *> &owner, const T **out, const std
   T *p = nullptr;
   int rc = dev_alloc(c, owner, &p, host.size());
   if (rc != MIRT_OK) return rc;
-  if (!host.empty()) HIP_TRY(c, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  if (!host.empty()) HIP_TRY(c, copy_sync(c->stream, p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
   *out = p;
   return MIRT_OK;
 }
@@ -228,6 +240,28 @@ bool walk_terminates(const MirtBVHNode *nodes, uint32_t n) {
   return true;
 }
 
+// The traversal kernels read the two children of a node together and keep the right one on a
+// stack, so the tree must be what the reference's builder writes (src/bvh.rs:160-214): children
+// side by side behind their parent (left, left + 1), the left child's skip link on its sibling,
+// the right child's on the parent's, the root's on node 0.  Also returns the height of the tree
+// (the most entries a walk can have on its stack).
+bool pairs_and_height(const MirtBVHNode *nodes, uint32_t n, uint32_t &height) {
+  height = 0;
+  if (nodes[0].right != 0u) return false;
+  std::vector<uint32_t> depth(n, 0u);
+  for (uint32_t i = 0; i < n; ++i) {
+    const MirtBVHNode &nd = nodes[i];
+    if (nd.is_leaf != 0u) continue;
+    const uint32_t l = nd.left;
+    if (l <= i || l + 1u >= n || l + 1u < l) return false;
+    if (nodes[l].right != l + 1u || nodes[l + 1u].right != nd.right) return false;
+    if (depth[l] != 0u || depth[l + 1u] != 0u) return false;  // a node has one parent
+    depth[l] = depth[l + 1u] = depth[i] + 1u;
+    if (depth[l] > height) height = depth[l];
+  }
+  return true;
+}
+
 // Every index a kernel will follow is checked here, once, so that no launch
 // can read outside its buffers or walk forever.
 // The instance-dependent part: instances, transforms, materials, TLAS, lights,
@@ -239,6 +273,7 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
   if (!d->materials || !d->n_materials || !d->transforms || !d->n_transforms) return bad("missing materials/transforms");
   if (!d->tlas_nodes || !d->n_tlas_nodes || !d->tlas_to_instances) return bad("missing TLAS buffers");
   if (d->n_tlas_nodes > kMaxNodesPerTree) return bad("TLAS has more than 2^24 nodes");
+  if (d->n_tlas_to_instances > kMaxNodesPerTree) return bad("TLAS has more than 2^24 leaf slots");
   for (uint32_t i = 0; i < d->n_instances; ++i)
     if (d->instances[i].transform >= d->n_transforms || d->instances[i].geometry >= d->n_geometries ||
         d->instances[i].material >= d->n_materials)
@@ -256,6 +291,9 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
     }
   }
   if (!walk_terminates(d->tlas_nodes, d->n_tlas_nodes)) return bad("TLAS links form a cycle");
+  uint32_t height = 0;
+  if (!pairs_and_height(d->tlas_nodes, d->n_tlas_nodes, height))
+    return bad("TLAS is not laid out as the reference's builder lays a tree out (children side by side, threaded)");
   if (d->n_light_sources != 0 && !d->light_sources) return bad("light_sources is null");
   const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
   if (!no_lights)
@@ -329,6 +367,9 @@ bool validate_geometry(const MirtSceneDesc *d, std::string &why) {
       }
     }
     if (!walk_terminates(d->blas_nodes + o.blas_node, nn)) return bad("BLAS links form a cycle");
+    uint32_t height = 0;
+    if (!pairs_and_height(d->blas_nodes + o.blas_node, nn, height))
+      return bad("a BLAS is not laid out as the reference's builder lays a tree out (children side by side, threaded)");
     for (uint32_t i = 0; i < ni; ++i)
       for (int k = 0; k < 3; ++k)
         if (d->indices[o.index + i].v[k] >= nv) return bad("vertex index out of range");
@@ -564,8 +605,32 @@ int mirt_destroy(mirt_ctx *ctx) {
   if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
   if (ctx->d_trace_counts) (void)hipFree(ctx->d_trace_counts);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
+  if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  return MIRT_OK;
+}
+
+// Spill rows of the walk's stack (DScene::stack_spill): one 8-byte entry per lane of the traversal
+// grid and row, rows for whatever the tallest TLAS walk + BLAS walk can defer beyond the entries a
+// lane keeps in LDS.  The TLAS gets headroom so that it can grow in place.  The stream must be idle.
+static int reserve_stack(mirt_ctx *ctx, DScene &sc, uint32_t tlas_height) {
+  if (tlas_height > ctx->tlas_height_room || ctx->tlas_height_room == 0u) ctx->tlas_height_room = tlas_height + 16u;
+  const uint64_t deepest = (uint64_t)ctx->blas_height + ctx->tlas_height_room + 1u;
+  const uint64_t rows = deepest > kStackLds ? deepest - kStackLds : 0u;
+  const uint64_t bytes = rows * (uint64_t)trace_grid_lanes(ctx->num_cus) * 8u;
+  if (bytes > 0xFFFFFFF0ull) return fail(ctx, MIRT_ERR_BAD_SCENE, "the trees are too tall for the traversal stack");
+  if (bytes > ctx->stack_spill_bytes) {
+    if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
+    ctx->stack_spill = nullptr;
+    ctx->stack_spill_bytes = 0;
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, (size_t)bytes));
+    ctx->stack_spill = static_cast<unsigned char *>(p);
+    ctx->stack_spill_bytes = (size_t)bytes;
+  }
+  sc.stack_spill = ctx->stack_spill;
+  sc.stack_spill_bytes = (uint32_t)ctx->stack_spill_bytes;
   return MIRT_OK;
 }
 
@@ -580,6 +645,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   ctx->geom_root_start.assign(d->n_geometries, 0);
   ctx->geom_root_count.assign(d->n_geometries, 0);
   ctx->geom_aabbs6.clear();
+  ctx->blas_height = 0;
   // Host staging is written exactly once: the big arrays are left uninitialised
   // (value-initialising 150 MB costs more than packing it) and the triangles are
   // packed straight into the geometry buffer once its layout is known.
@@ -613,6 +679,9 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     // triangle of its geometry — which is what the reference's builder leaves
     // in them (src/bvh.rs:144-151); a leaf root's range has been validated.
     const MirtBVHNode &root = d->blas_nodes[o.blas_node];
+    uint32_t height = 0;
+    (void)pairs_and_height(d->blas_nodes + o.blas_node, nn, height);  // the layout was checked by validate_geometry
+    if (height > ctx->blas_height) ctx->blas_height = height;
     ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.lb, root.lb + 3);
     ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.ub, root.ub + 3);
     const uint32_t idx_end_g = last ? d->n_indices : d->geometry_offsets[g + 1].index;
@@ -737,7 +806,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   unsigned char *pg = nullptr;
   int rc = dev_alloc(ctx, ctx->scene_allocs, &pg, geo_bytes);
   if (rc != MIRT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpy(pg, geo.get(), geo_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, copy_sync(ctx->stream, pg, geo.get(), geo_bytes, hipMemcpyHostToDevice));
   sc.geo = pg;
   sc.geo_bytes = (uint32_t)geo_bytes;
   sc.tri_off = (uint32_t)tri_off;
@@ -748,7 +817,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   if (!cache_image.empty() && (rc = dev_upload(ctx, ctx->scene_allocs, &sc.leaf_cache, cache_image)) != MIRT_OK) return rc;
   DTriN *ptn = nullptr;
   if ((rc = dev_alloc(ctx, ctx->scene_allocs, &ptn, d->n_indices)) != MIRT_OK) return rc;
-  if (d->n_indices) HIP_TRY(ctx, hipMemcpy(ptn, trins.get(), (size_t)d->n_indices * sizeof(DTriN), hipMemcpyHostToDevice));
+  if (d->n_indices) HIP_TRY(ctx, copy_sync(ctx->stream, ptn, trins.get(), (size_t)d->n_indices * sizeof(DTriN), hipMemcpyHostToDevice));
   sc.trin = ptn;
   sc.tri_uv = nullptr;
   if (d->n_textures) {
@@ -769,7 +838,7 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     }
     float *puv = nullptr;
     if ((rc = dev_alloc(ctx, ctx->scene_allocs, &puv, (size_t)8 * d->n_indices)) != MIRT_OK) return rc;
-    if (d->n_indices) HIP_TRY(ctx, hipMemcpy(puv, uvs.get(), (size_t)32 * d->n_indices, hipMemcpyHostToDevice));
+    if (d->n_indices) HIP_TRY(ctx, copy_sync(ctx->stream, puv, uvs.get(), (size_t)32 * d->n_indices, hipMemcpyHostToDevice));
     sc.tri_uv = reinterpret_cast<const float4 *>(puv);
   }
   return MIRT_OK;
@@ -782,10 +851,15 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   auto &own = ctx->instance_allocs;
   int rc;
   {
+    uint32_t tlas_height = 0;
+    (void)pairs_and_height(d->tlas_nodes, d->n_tlas_nodes, tlas_height);  // the layout was checked by validate_instances
+    if ((rc = reserve_stack(ctx, sc, tlas_height)) != MIRT_OK) return rc;
+  }
+  {
     std::vector<DNode> tlas(d->n_tlas_nodes);
     std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
     pack_nodes(d->tlas_nodes, d->n_tlas_nodes, tlas.data(), tlas_sizes.data(), true);
-    HIP_TRY(ctx, hipMemcpy(const_cast<DNode *>(sc.nodes) + sc.tlas_base, tlas.data(), tlas.size() * sizeof(DNode),
+    HIP_TRY(ctx, copy_sync(ctx->stream, const_cast<DNode *>(sc.nodes) + sc.tlas_base, tlas.data(), tlas.size() * sizeof(DNode),
                            hipMemcpyHostToDevice));
     // a leaf of kBigLeaf or more slots keeps its size out of line, indexed by its first slot
     std::vector<uint32_t> big(d->n_tlas_to_instances ? d->n_tlas_to_instances : 1u, 0u);
@@ -873,6 +947,7 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
   free_all(ctx->scene_allocs);
   free_all(ctx->instance_allocs);
   ctx->have_scene = false;
+  ctx->tlas_height_room = 0;
   DScene sc{};
   int rc = upload_geometry(ctx, d, sc);
   if (rc == MIRT_OK) rc = upload_instances(ctx, d, sc);
@@ -938,6 +1013,7 @@ int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
   res.capacity = ctx->tlas_capacity;
   res.big = const_cast<uint32_t *>(ctx->sc.tlas_big);
   res.to_inst = const_cast<uint32_t *>(ctx->sc.tlas_to_inst);
+  res.max_height = ctx->tlas_height_room;
   uint32_t n_nodes = 0;
   std::string err;
   const int rc = build_tlas_device(ctx->stream, ctx->geom_aabbs6.data(), ctx->n_geometries, mats.data(), geom.data(), n,
@@ -987,25 +1063,25 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if ((rc = dev_alloc(ctx, own, &st.sample_index, 1)) != MIRT_OK) return rc;
   MirtSampleSource *dsrc = nullptr;
   if ((rc = dev_alloc(ctx, own, &dsrc, n_sources)) != MIRT_OK) return rc;
-  HIP_TRY(ctx, hipMemcpy(dsrc, sources, (size_t)n_sources * sizeof(MirtSampleSource), hipMemcpyHostToDevice));
+  HIP_TRY(ctx, copy_sync(ctx->stream, dsrc, sources, (size_t)n_sources * sizeof(MirtSampleSource), hipMemcpyHostToDevice));
   st.sources = dsrc;
   if ((rc = dev_alloc(ctx, own, &st.sum4, (size_t)4 * n_sources)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.count, n_sources)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.output, (size_t)width * height)) != MIRT_OK) return rc;
-  HIP_TRY(ctx, hipMemset(st.sum4, 0, (size_t)16 * n_sources));
-  HIP_TRY(ctx, hipMemset(st.count, 0, (size_t)4 * n_sources));
-  HIP_TRY(ctx, hipMemset(st.output, 0, (size_t)4 * width * height));
-  HIP_TRY(ctx, hipMemset(st.stats, 0, S_COUNT * sizeof(unsigned long long)));
-  HIP_TRY(ctx, hipMemset(st.qcount, 0, QW_COUNT * sizeof(uint32_t)));
-  HIP_TRY(ctx, hipMemset(st.sample_index, 0, sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemsetAsync(st.sum4, 0, (size_t)16 * n_sources, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.count, 0, (size_t)4 * n_sources, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.output, 0, (size_t)4 * width * height, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.stats, 0, S_COUNT * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.qcount, 0, QW_COUNT * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.sample_index, 0, sizeof(unsigned long long), ctx->stream));
   st.n_active = n_sources;
   st.active = nullptr;
   ctx->d_active = nullptr;
   if ((rc = dev_alloc(ctx, own, &st.flags, n_sources)) != MIRT_OK) return rc;
-  HIP_TRY(ctx, hipMemset(st.flags, 0, (size_t)4 * n_sources));
+  HIP_TRY(ctx, hipMemsetAsync(st.flags, 0, (size_t)4 * n_sources, ctx->stream));
   if (params->adaptive) {
     if ((rc = dev_alloc(ctx, own, &st.moments, (size_t)2 * n_sources)) != MIRT_OK) return rc;
-    HIP_TRY(ctx, hipMemset(st.moments, 0, (size_t)16 * n_sources));
+    HIP_TRY(ctx, hipMemsetAsync(st.moments, 0, (size_t)16 * n_sources, ctx->stream));
     if ((rc = dev_alloc(ctx, own, &ctx->d_active, n_sources)) != MIRT_OK) return rc;
     // sources the caller hands over flagged are skipped from the start
     std::vector<uint32_t> flags(n_sources), act;
@@ -1017,15 +1093,15 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
     if (any) {
       for (uint32_t i = 0; i < n_sources; ++i)
         if (!flags[i]) act.push_back(i);
-      HIP_TRY(ctx, hipMemcpy(st.flags, flags.data(), (size_t)4 * n_sources, hipMemcpyHostToDevice));
-      if (!act.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(ctx, copy_sync(ctx->stream, st.flags, flags.data(), (size_t)4 * n_sources, hipMemcpyHostToDevice));
+      if (!act.empty()) HIP_TRY(ctx, copy_sync(ctx->stream, ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
       st.active = ctx->d_active;
       st.n_active = (uint32_t)act.size();
     }
   }
   if (params->rng_mode == MIRT_RNG_PER_SLOT) {
     if ((rc = dev_alloc(ctx, own, &st.slot_stamp, threads)) != MIRT_OK) return rc;
-    HIP_TRY(ctx, hipMemset(st.slot_stamp, 0, (size_t)4 * threads));
+    HIP_TRY(ctx, hipMemsetAsync(st.slot_stamp, 0, (size_t)4 * threads, ctx->stream));
   }
   ctx->st = st;
   ctx->params = *params;
@@ -1079,7 +1155,7 @@ int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, 
   if (act.size() == ctx->st.n_sources) {
     ctx->st.active = nullptr;
   } else {
-    if (!act.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
+    if (!act.empty()) HIP_TRY(ctx, copy_sync(ctx->stream, ctx->d_active, act.data(), act.size() * 4, hipMemcpyHostToDevice));
     ctx->st.active = ctx->d_active;
   }
   ctx->st.n_active = (uint32_t)act.size();
@@ -1274,8 +1350,8 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
   if ((rc = dev_alloc(ctx, tmp, &d_rays, n)) != MIRT_OK) { free_all(tmp); return rc; }
   if ((rc = dev_alloc(ctx, tmp, &d_out, n)) != MIRT_OK) { free_all(tmp); return rc; }
   if (any_hit && (rc = dev_alloc(ctx, tmp, &d_tmax, n)) != MIRT_OK) { free_all(tmp); return rc; }
-  hipError_t e = hipMemcpy(d_rays, rays, n * sizeof(MirtRay), hipMemcpyHostToDevice);
-  if (e == hipSuccess && any_hit) e = hipMemcpy(d_tmax, tmax, n * 4, hipMemcpyHostToDevice);
+  hipError_t e = copy_sync(ctx->stream, d_rays, rays, n * sizeof(MirtRay), hipMemcpyHostToDevice);
+  if (e == hipSuccess && any_hit) e = copy_sync(ctx->stream, d_tmax, tmax, n * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemsetAsync(ctx->d_trace_counts, 0, 6 * sizeof(unsigned long long), ctx->stream);
   if (e != hipSuccess) { free_all(tmp); return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e)); }
   LaunchCfg cfg;
@@ -1308,10 +1384,10 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
     e = hipStreamSynchronize(ctx->stream);
   }
   if (e == hipSuccess) e = hipGetLastError();
-  if (e == hipSuccess && out) e = hipMemcpy(out, d_out, n * sizeof(MirtHitId), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && out) e = copy_sync(ctx->stream, out, d_out, n * sizeof(MirtHitId), hipMemcpyDeviceToHost);
   if (e == hipSuccess && counts) {
     unsigned long long h[5];
-    e = hipMemcpy(h, ctx->d_trace_counts, sizeof(h), hipMemcpyDeviceToHost);
+    e = copy_sync(ctx->stream, h, ctx->d_trace_counts, sizeof(h), hipMemcpyDeviceToHost);
     counts->rays = h[0]; counts->tlas_nodes = h[1]; counts->instance_visits = h[2];
     counts->blas_nodes = h[3]; counts->triangles = h[4];
   }
@@ -1443,7 +1519,7 @@ int mirt_stats_reset(mirt_ctx *ctx) {
   if (ctx->have_state) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ev_collect(ctx);
-    HIP_TRY(ctx, hipMemset(ctx->st.stats, 0, S_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->st.stats, 0, S_COUNT * sizeof(unsigned long long), ctx->stream));
   }
   for (int k = 0; k < K_KINDS; ++k) { ctx->kernel_ms[k] = 0.0; ctx->kernel_launches[k] = 0; }
   ctx->frames_total = 0;
@@ -1472,12 +1548,12 @@ int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_
   // bounce rays pushed by the last shade launch
   const uint32_t par = ctx->frame & 1u;
   uint32_t cnt = 0;
-  HIP_TRY(ctx, hipMemcpy(&cnt, ctx->st.qcount + Q_EXT0 + par, 4, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, copy_sync(ctx->stream, &cnt, ctx->st.qcount + Q_EXT0 + par, 4, hipMemcpyDeviceToHost));
   if (cnt > ctx->st.slots) return fail(ctx, MIRT_ERR_HIP, "dump: queue count exceeds slots");
   std::vector<uint32_t> idx(cnt);
-  if (cnt) HIP_TRY(ctx, hipMemcpy(idx.data(), ctx->st.qdata[Q_EXT0 + par], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+  if (cnt) HIP_TRY(ctx, copy_sync(ctx->stream, idx.data(), ctx->st.qdata[Q_EXT0 + par], (size_t)cnt * 4, hipMemcpyDeviceToHost));
   std::vector<MirtRay> all(ctx->st.slots);
-  HIP_TRY(ctx, hipMemcpy(all.data(), ctx->st.ray, (size_t)ctx->st.slots * sizeof(MirtRay), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, copy_sync(ctx->stream, all.data(), ctx->st.ray, (size_t)ctx->st.slots * sizeof(MirtRay), hipMemcpyDeviceToHost));
   size_t w = 0;
   for (uint32_t k = 0; k < cnt && w < capacity; ++k) out[w++] = all[idx[k]];
   *n_written = w;
@@ -1496,14 +1572,14 @@ int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const floa
     free_all(tmp);
     return rc;
   }
-  hipError_t e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dc, c, n * 4, hipMemcpyHostToDevice);
+  hipError_t e = copy_sync(ctx->stream, da, a, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(ctx->stream, db, b, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = copy_sync(ctx->stream, dc, c, n * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     launch_math_selftest(ctx->stream, da, db, dc, n, dout);
     e = hipStreamSynchronize(ctx->stream);
   }
-  if (e == hipSuccess) e = hipMemcpy(out6, dout, 6 * n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = copy_sync(ctx->stream, out6, dout, 6 * n * 4, hipMemcpyDeviceToHost);
   free_all(tmp);
   if (e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e));
   return MIRT_OK;

@@ -919,6 +919,8 @@ int trace_grid_blocks(int num_cus) {
   return it->second * num_cus;
 }
 
+size_t trace_grid_lanes(int num_cus) { return (size_t)trace_grid_blocks(num_cus) * kEngineBlock; }
+
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (fp.counting) hipLaunchKernelGGL((k_extend<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
