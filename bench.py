@@ -98,7 +98,7 @@ def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
             "sample": f"first {n2} of {len(src)} sample sources of the same workload, {spp} spp, {rays} rays in {dt:.2f} s"}
 
 
-DEVICE_SOURCES = ["engine.h", "walk_threaded.h", "walk_pairs.h", "kernels.hip", "kernels.h", "layout.h", "device_util.h", "rt_math.h",
+DEVICE_SOURCES = ["engine.h", "kernels.hip", "kernels.h", "layout.h", "device_util.h", "rt_math.h",
                   "classic.hip", "api.hip"]
 
 

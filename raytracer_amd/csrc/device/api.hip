@@ -75,10 +75,6 @@ struct mirt_ctx {
   std::vector<void *> instance_allocs;  // what mirt_scene_update_instances replaces
   uint32_t n_instances = 0, n_geometries = 0;
   uint32_t tlas_capacity = 0;  // nodes reserved for the TLAS at the front of the node array
-  // the walk's stack: tallest BLAS, the TLAS height the spill rows allow for, the rows themselves
-  uint32_t blas_height = 0, tlas_height_room = 0;
-  unsigned char *stack_spill = nullptr;
-  size_t stack_spill_bytes = 0;
   std::vector<uint32_t> geom_node_base, geom_tri_base, geom_root_start, geom_root_count;
   // kept for mirt_scene_update_transforms: each geometry's root box, the instances and their device records
   std::vector<float> geom_aabbs6;
@@ -240,28 +236,6 @@ bool walk_terminates(const MirtBVHNode *nodes, uint32_t n) {
   return true;
 }
 
-// The traversal kernels read the two children of a node together and keep the right one on a
-// stack, so the tree must be what the reference's builder writes (src/bvh.rs:160-214): children
-// side by side behind their parent (left, left + 1), the left child's skip link on its sibling,
-// the right child's on the parent's, the root's on node 0.  Also returns the height of the tree
-// (the most entries a walk can have on its stack).
-bool pairs_and_height(const MirtBVHNode *nodes, uint32_t n, uint32_t &height) {
-  height = 0;
-  if (nodes[0].right != 0u) return false;
-  std::vector<uint32_t> depth(n, 0u);
-  for (uint32_t i = 0; i < n; ++i) {
-    const MirtBVHNode &nd = nodes[i];
-    if (nd.is_leaf != 0u) continue;
-    const uint32_t l = nd.left;
-    if (l <= i || l + 1u >= n || l + 1u < l) return false;
-    if (nodes[l].right != l + 1u || nodes[l + 1u].right != nd.right) return false;
-    if (depth[l] != 0u || depth[l + 1u] != 0u) return false;  // a node has one parent
-    depth[l] = depth[l + 1u] = depth[i] + 1u;
-    if (depth[l] > height) height = depth[l];
-  }
-  return true;
-}
-
 // Every index a kernel will follow is checked here, once, so that no launch
 // can read outside its buffers or walk forever.
 // The instance-dependent part: instances, transforms, materials, TLAS, lights,
@@ -273,7 +247,6 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
   if (!d->materials || !d->n_materials || !d->transforms || !d->n_transforms) return bad("missing materials/transforms");
   if (!d->tlas_nodes || !d->n_tlas_nodes || !d->tlas_to_instances) return bad("missing TLAS buffers");
   if (d->n_tlas_nodes > kMaxNodesPerTree) return bad("TLAS has more than 2^24 nodes");
-  if (d->n_tlas_to_instances > kMaxNodesPerTree) return bad("TLAS has more than 2^24 leaf slots");
   for (uint32_t i = 0; i < d->n_instances; ++i)
     if (d->instances[i].transform >= d->n_transforms || d->instances[i].geometry >= d->n_geometries ||
         d->instances[i].material >= d->n_materials)
@@ -291,9 +264,6 @@ bool validate_instances(const MirtSceneDesc *d, std::string &why) {
     }
   }
   if (!walk_terminates(d->tlas_nodes, d->n_tlas_nodes)) return bad("TLAS links form a cycle");
-  uint32_t height = 0;
-  if (!pairs_and_height(d->tlas_nodes, d->n_tlas_nodes, height))
-    return bad("TLAS is not laid out as the reference's builder lays a tree out (children side by side, threaded)");
   if (d->n_light_sources != 0 && !d->light_sources) return bad("light_sources is null");
   const bool no_lights = d->n_light_sources == 0 || (d->n_light_sources == 1 && d->light_sources[0] == 0xFFFFFFFFu);
   if (!no_lights)
@@ -367,9 +337,6 @@ bool validate_geometry(const MirtSceneDesc *d, std::string &why) {
       }
     }
     if (!walk_terminates(d->blas_nodes + o.blas_node, nn)) return bad("BLAS links form a cycle");
-    uint32_t height = 0;
-    if (!pairs_and_height(d->blas_nodes + o.blas_node, nn, height))
-      return bad("a BLAS is not laid out as the reference's builder lays a tree out (children side by side, threaded)");
     for (uint32_t i = 0; i < ni; ++i)
       for (int k = 0; k < 3; ++k)
         if (d->indices[o.index + i].v[k] >= nv) return bad("vertex index out of range");
@@ -605,32 +572,8 @@ int mirt_destroy(mirt_ctx *ctx) {
   if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
   if (ctx->d_trace_counts) (void)hipFree(ctx->d_trace_counts);
   if (ctx->build_ws) (void)hipFree(ctx->build_ws);
-  if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
-  return MIRT_OK;
-}
-
-// Spill rows of the walk's stack (DScene::stack_spill): one 8-byte entry per lane of the traversal
-// grid and row, rows for whatever the tallest TLAS walk + BLAS walk can defer beyond the entries a
-// lane keeps in LDS.  The TLAS gets headroom so that it can grow in place.  The stream must be idle.
-static int reserve_stack(mirt_ctx *ctx, DScene &sc, uint32_t tlas_height) {
-  if (tlas_height > ctx->tlas_height_room || ctx->tlas_height_room == 0u) ctx->tlas_height_room = tlas_height + 16u;
-  const uint64_t deepest = (uint64_t)ctx->blas_height + ctx->tlas_height_room + 1u;
-  const uint64_t rows = deepest > kStackLds ? deepest - kStackLds : 0u;
-  const uint64_t bytes = rows * (uint64_t)trace_grid_lanes(ctx->num_cus) * 8u;
-  if (bytes > 0xFFFFFFF0ull) return fail(ctx, MIRT_ERR_BAD_SCENE, "the trees are too tall for the traversal stack");
-  if (bytes > ctx->stack_spill_bytes) {
-    if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
-    ctx->stack_spill = nullptr;
-    ctx->stack_spill_bytes = 0;
-    void *p = nullptr;
-    HIP_TRY(ctx, hipMalloc(&p, (size_t)bytes));
-    ctx->stack_spill = static_cast<unsigned char *>(p);
-    ctx->stack_spill_bytes = (size_t)bytes;
-  }
-  sc.stack_spill = ctx->stack_spill;
-  sc.stack_spill_bytes = (uint32_t)ctx->stack_spill_bytes;
   return MIRT_OK;
 }
 
@@ -645,7 +588,6 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   ctx->geom_root_start.assign(d->n_geometries, 0);
   ctx->geom_root_count.assign(d->n_geometries, 0);
   ctx->geom_aabbs6.clear();
-  ctx->blas_height = 0;
   // Host staging is written exactly once: the big arrays are left uninitialised
   // (value-initialising 150 MB costs more than packing it) and the triangles are
   // packed straight into the geometry buffer once its layout is known.
@@ -679,9 +621,6 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     // triangle of its geometry — which is what the reference's builder leaves
     // in them (src/bvh.rs:144-151); a leaf root's range has been validated.
     const MirtBVHNode &root = d->blas_nodes[o.blas_node];
-    uint32_t height = 0;
-    (void)pairs_and_height(d->blas_nodes + o.blas_node, nn, height);  // the layout was checked by validate_geometry
-    if (height > ctx->blas_height) ctx->blas_height = height;
     ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.lb, root.lb + 3);
     ctx->geom_aabbs6.insert(ctx->geom_aabbs6.end(), root.ub, root.ub + 3);
     const uint32_t idx_end_g = last ? d->n_indices : d->geometry_offsets[g + 1].index;
@@ -851,11 +790,6 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   auto &own = ctx->instance_allocs;
   int rc;
   {
-    uint32_t tlas_height = 0;
-    (void)pairs_and_height(d->tlas_nodes, d->n_tlas_nodes, tlas_height);  // the layout was checked by validate_instances
-    if ((rc = reserve_stack(ctx, sc, tlas_height)) != MIRT_OK) return rc;
-  }
-  {
     std::vector<DNode> tlas(d->n_tlas_nodes);
     std::vector<uint32_t> tlas_sizes(d->n_tlas_nodes);
     pack_nodes(d->tlas_nodes, d->n_tlas_nodes, tlas.data(), tlas_sizes.data(), true);
@@ -947,7 +881,6 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
   free_all(ctx->scene_allocs);
   free_all(ctx->instance_allocs);
   ctx->have_scene = false;
-  ctx->tlas_height_room = 0;
   DScene sc{};
   int rc = upload_geometry(ctx, d, sc);
   if (rc == MIRT_OK) rc = upload_instances(ctx, d, sc);
@@ -1013,7 +946,6 @@ int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
   res.capacity = ctx->tlas_capacity;
   res.big = const_cast<uint32_t *>(ctx->sc.tlas_big);
   res.to_inst = const_cast<uint32_t *>(ctx->sc.tlas_to_inst);
-  res.max_height = ctx->tlas_height_room;
   uint32_t n_nodes = 0;
   std::string err;
   const int rc = build_tlas_device(ctx->stream, ctx->geom_aabbs6.data(), ctx->n_geometries, mats.data(), geom.data(), n,

@@ -921,8 +921,7 @@ struct Carver {
 // The tree over the prepared elements (boxes, centroids, identity order in bb): root, level
 // loop, then the reference's numbering and skip links into d_out.  `n_elems` = bb.nf.
 static int grow_tree(hipStream_t stream, BuildBufs &bb, uint32_t n_faces, size_t cap, size_t max_huge, size_t max_chunks,
-                     unsigned long long *root_keys, MirtBVHNode *d_out, uint32_t *total_out, std::string &err,
-                     uint32_t *height_out = nullptr) {
+                     unsigned long long *root_keys, MirtBVHNode *d_out, uint32_t *total_out, std::string &err) {
   BUILD_TRY(hipMemsetAsync(root_keys, 0xFF, 6 * sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k_build_root_keys, dim3((n_faces + kBuildChunk - 1u) / kBuildChunk), dim3(1024), 0, stream, bb, root_keys);
   hipLaunchKernelGGL(k_build_root, dim3(1), dim3(64), 0, stream, bb, root_keys);
@@ -983,7 +982,6 @@ static int grow_tree(hipStream_t stream, BuildBufs &bb, uint32_t n_faces, size_t
   for (size_t l = 0; l < levels.size(); ++l)
     hipLaunchKernelGGL(k_build_down, dim3((levels[l].second + 255u) / 256u), dim3(256), 0, stream, bb, levels[l].first, levels[l].second, d_out);
   *total_out = total;
-  if (height_out) *height_out = (uint32_t)levels.size() - 1u;  // a level is the nodes of one depth
   return MIRT_OK;
 }
 
@@ -1146,15 +1144,15 @@ int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_g
   } guard{ev0, ev1};
   BUILD_TRY(hipEventRecord(ev0, stream));
   hipLaunchKernelGGL(k_tlas_prep, dim3((n + 255u) / 256u), dim3(256), 0, stream, bb, d_aabbs, d_mats, d_geom);
-  uint32_t total = 0, height = 0;
+  uint32_t total = 0;
   {
-    const int rc = grow_tree(stream, bb, n, cap, max_huge, max_chunks, root_keys, d_out, &total, err, &height);
+    const int rc = grow_tree(stream, bb, n, cap, max_huge, max_chunks, root_keys, d_out, &total, err);
     if (rc != MIRT_OK) return rc;
   }
   if (resident != nullptr) {
     // stay on the device: pack straight into the scene's TLAS block
     *n_nodes = total;
-    if (total > resident->capacity || height > resident->max_height) {
+    if (total > resident->capacity) {
       err = "update_transforms: the TLAS outgrew the room reserved for it";
       return MIRT_ERR_INVALID_ARGUMENT;
     }

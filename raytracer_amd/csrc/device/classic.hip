@@ -110,7 +110,7 @@ __device__ __forceinline__ float lambert_pdf(v3 wi, v3 n) { return fmax_nn(0.0f,
 // shadow ray as an any-hit query, writes the slot's ShadowData and routes the
 // slot to the queue of its hit material.
 template <bool COUNT>
-__global__ __launch_bounds__(kEngineBlock) void k_connect(DScene sc, DState st, DFrameParams fp) {
+__global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams fp) {
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
   LaneCounts lc;

@@ -11,13 +11,15 @@
 //
 // What differs from the shader is scheduling (details at trace_engine):
 //   - the nested do-while loops are flattened into per-lane state machines
-//     driven by ONE wave-uniform loop, so lanes in different instances, at
-//     different depths, on nodes or on triangles run the same instructions;
-//   - a leaf with kCoopLeaf or more triangles (the builder leaves such leaves
+//     driven by ONE wave-uniform loop that only walks nodes, so lanes in different
+//     instances and at different depths run the same instructions; a lane that hits a
+//     leaf waits for the wave's next service point;
+//   - there a leaf with kCoopLeaf or more triangles (the builder leaves such leaves
 //     behind when its partition puts everything on one side) is tested by the
-//     whole wave, 64 triangles per step, for the lane that reached it.  A scan
+//     whole wave, 64 triangles per pass, and smaller leaves four lanes to a leaf,
+//     sixteen leaves per pass, for the lane that reached it.  A sequential scan
 //     accepts every triangle with t2 <= current t, so it ends on the smallest
-//     t2 and, among equal t2, on the highest index: the wave computes exactly
+//     t2 and, among equal t2, on the highest index: the lanes compute exactly
 //     that with a min-reduction on (t2, -index); u, v, t2 of a triangle do not
 //     depend on the current t, so the bits match;
 //   - rays differ wildly in cost, so a wave does not wait for its slowest ray:
@@ -184,21 +186,465 @@ struct WorkSource {
 // leaf cache, which every wave of the CU shares, up to 64 KB more.
 constexpr uint32_t kEngineBlock = MIRT_ENGINE_BLOCK;
 // the leaf cache needs the one-block-per-CU shape; smaller blocks go without
-constexpr uint32_t kLeafCacheWords16 = kEngineBlock == 1024u ? kLeafCacheBytes / 16u : 0u;
+constexpr uint32_t kLeafCacheWords16 = kEngineBlock >= 512u ? kLeafCacheBytes / 16u : 0u;
+// resident waves per SIMD the engine kernels are compiled for (bounds their registers)
+#ifndef MIRT_ENGINE_WAVES_PER_SIMD
+#define MIRT_ENGINE_WAVES_PER_SIMD 4
+#endif
+#define MIRT_ENGINE_BOUNDS __launch_bounds__(kEngineBlock, MIRT_ENGINE_WAVES_PER_SIMD)
 constexpr uint32_t kNoExclude = 0xFFFFFFFFu;
 
-// Two walks produce the same hits, visit counts and bits: the threaded one (one node per
-// fetch, as the shader walks) and the one that reads sibling nodes together and defers the
-// right one on a stack (half the dependent fetches).  Both are bound by instruction issue on
-// the benchmark scenes and the threaded one issues fewer scalar instructions, so it is the default.
-#ifndef MIRT_WALK_PAIRS
-#define MIRT_WALK_PAIRS 0
+// Per-lane walk flags, kept in one vector register: as lane masks in scalar
+// registers every divergent update would cost a three-instruction merge.
+enum : uint32_t {
+  F_HAS = 1u,     // the lane holds a ray
+  F_WALK = 2u,    // ... that is still walking
+  F_FOUND = 4u,   // a triangle has been accepted
+  F_BLAS = 8u,    // the tree being walked is an instance's BLAS
+  F_WRAP = 16u,   // the cursor is back at the root: this tree is done
+  F_TDONE = 32u,  // the TLAS cursor has wrapped (instances of its last leaf may remain)
+  F_HOLD = 64u    // no step until the service point has dealt with the lane
+};
+
+#ifndef MIRT_STEPS_PER_CHECK
+#define MIRT_STEPS_PER_CHECK 8
 #endif
-#if MIRT_WALK_PAIRS
-#include "walk_pairs.h"
-#else
-#include "walk_threaded.h"
-#endif
+constexpr int kStepsPerCheck = MIRT_STEPS_PER_CHECK;  // steps between two looks at the service condition
+
+using BufferRsrc = __amdgpu_buffer_rsrc_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// the value of lane ^ 1 / lane ^ 2 within each group of four lanes (one data-parallel move each)
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+}
+
+// 16 bytes at byte offset `off` of the geometry buffer; offsets past its end read zero.
+__device__ __forceinline__ float4 geo_load16(BufferRsrc rsrc, uint32_t off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
+  return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
+}
+
+// The engine.  `fetch(index, ray)` loads entry `index` of the client's queue
+// (called by single lanes); `finish(fin, payload, found, t, best)` is called by
+// ALL lanes at every refill point, with fin = true on the lanes whose ray is
+// done, so it may use wave-aggregated pushes.
+//
+// The kernels built on it are bound by instruction issue, and lanes of a wave are on nodes
+// and on triangles in a ratio of about five to one: a step that serves both kinds runs the
+// triangle test for a handful of lanes.  So the step loop here only walks nodes (one 32-byte
+// fetch, one box test per lane and step), and a lane that hits a leaf waits for the service
+// point, entered when a quarter of the walking lanes wait.  There
+//   - leaves of kCoopLeaf triangles or more are scanned by the whole wave, 64 per pass;
+//   - the small leaves (the builder's leaves hold up to four triangles, its bail-outs more)
+//     are tested four lanes to a leaf, sixteen leaves per pass: each lane takes every fourth
+//     triangle with the owner's ray (pulled across lanes), the four reduce to the winner —
+//     smallest t2, among equal t2 the highest index, which is what the shader's sequential
+//     scan with `t2 <= t` ends on — and the owner pulls it back;
+//   - housekeeping, hand-over of finished rays and refill follow as in the plain walk.
+// Everything a lane keeps per ray lives in registers; LDS holds the leaf cache and a
+// 64-entry list per wave.
+template <bool ANY, bool COUNT, class Fetch, class Finish>
+__device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource ws, LaneCounts &lc, Fetch fetch,
+                                             Finish finish) {
+  __shared__ uint32_t s_own[kEngineBlock / 64u][64];  // per wave: the lanes that wait with a small leaf, in lane order
+  __shared__ uint4 s_cache[kLeafCacheWords16 ? kLeafCacheWords16 : 1u];  // the scene's leaf-cache image (layout.h)
+  const uint32_t tid = threadIdx.x;
+  if (kLeafCacheWords16 != 0u) {
+    const uint32_t n16 = sc.leaf_cache_bytes / 16u < kLeafCacheWords16 ? sc.leaf_cache_bytes / 16u : kLeafCacheWords16;
+    for (uint32_t i = tid; i < n16; i += kEngineBlock) s_cache[i] = sc.leaf_cache[i];
+    __syncthreads();
+  }
+  const uint32_t lane = trv_lane();
+  const BufferRsrc geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(sc.geo), 0, (int)sc.geo_bytes, 0x00020000);
+  const uint32_t tlas_nbase = sc.tlas_base * 32u;
+
+  // wave-uniform work cursor
+  uint32_t chunk_next = 0, chunk_end = 0;
+  bool exhausted = false;
+
+  // per-lane walk state
+  uint32_t fl = 0u;
+  float t = FLT_MAX;
+  uint32_t cur = 0;                 // node under the cursor (index within its tree)
+  uint32_t nbase = 0, tbase = 0;    // byte offsets of the tree's node 0 and of the instance's triangle 0
+  uint32_t excl_prim = kNoExclude;  // the triangle of this instance the ray must not hit, if any
+  float tseed = 0.0f;               // what ray_box seeds tmin with: 0 in the TLAS, -FLT_MAX in a BLAS
+  // the ray in the space of the tree being walked (world for the TLAS)
+  v3 cpos = V3(0.0f, 0.0f, 0.0f), cdir = V3(1.0f, 1.0f, 1.0f), cdinv = V3(1.0f, 1.0f, 1.0f);
+  // what is left of the leaf the lane is on: count == 0 means none (BLAS: triangles, TLAS: slots)
+  uint32_t leaf_start = 0, leaf_count = 0;
+  // touched once per instance or per ray
+  v3 wpos = V3(0.0f, 0.0f, 0.0f), wdir = V3(1.0f, 1.0f, 1.0f);  // the world-space ray
+  uint32_t last_inst = 0, last_prim = 0, payload = 0;
+  uint32_t tlas_cur = 0, slot_next = 0, slot_stop = 0, cur_inst = 0;  // while in a BLAS: where the TLAS walk stands, the instance
+  float best_u = 0.0f, best_v = 0.0f;
+  uint32_t best_prim = 0, best_inst = 0;
+  uint32_t (&own)[64] = s_own[tid >> 6];
+  MIRT_PH_DECL;
+
+  auto accept = [&](float t2, float u, float v, uint32_t p) {
+    t = t2;
+    best_u = u;
+    best_v = v;
+    best_prim = p;
+    best_inst = cur_inst;
+    fl |= F_FOUND;
+    if (ANY) fl &= ~F_WALK;  // the first accepted triangle ends an any-hit query
+  };
+
+  while (true) {
+    const int n_walking = __popcll(__ballot((fl & F_WALK) != 0u));
+    const int n_held = __popcll(__ballot((fl & (F_WALK | F_HOLD)) == (F_WALK | F_HOLD)));
+    if ((n_held != 0 && kServiceFrac * n_held >= n_walking) || n_held == n_walking ||
+        (!exhausted && n_walking < kRefillBelow)) {
+      MIRT_PH_COUNT(0);
+      // ================================================== service point
+      // ------------------------------------- leaves for the whole wave
+      {
+        unsigned long long bigmask =
+            __ballot((fl & (F_WALK | F_HOLD | F_BLAS)) == (F_WALK | F_HOLD | F_BLAS) && leaf_count >= kCoopLeaf);
+        const bool any_big = bigmask != 0ull;
+        MIRT_PH_RESET;
+        while (bigmask != 0ull) {
+          const int owner = __ffsll((long long)bigmask) - 1;
+          bigmask &= bigmask - 1ull;
+          MIRT_PH_COUNT(3);
+          // the owner's ray and leaf, wave-uniform
+          // (the ray through a lane shuffle, so that it stays in vector registers: an
+          // operand read from a scalar register slows every instruction of the scan down)
+          auto bcast_f = [&](float x) { return __shfl(x, owner); };
+          auto bcast_u = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, owner); };
+          const v3 op = V3(bcast_f(cpos.x), bcast_f(cpos.y), bcast_f(cpos.z));
+          const v3 od = V3(bcast_f(cdir.x), bcast_f(cdir.y), bcast_f(cdir.z));
+          const float ot = bcast_f(t);
+          const uint32_t ostart = bcast_u(leaf_start);
+          const uint32_t otbase = bcast_u(tbase);
+          uint32_t ocount = bcast_u(leaf_count);
+          if (ocount == kBigLeaf) ocount = geo_load4(geo, otbase + ostart * 48u + 12u);  // size stored out of line
+          const uint32_t oskip = bcast_u(excl_prim);
+          // per-lane best over triangles ostart + lane, + 64, ...
+          // key: ANY -> index (first accepted in index order);
+          //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
+          unsigned long long key = ~0ull;
+          float ku = 0.0f, kv = 0.0f, kt = 0.0f;
+          // one triangle for this lane; returns true when the lane needs no further ones
+          auto consider = [&](uint32_t p, v3 p0, v3 e1, v3 e2) {
+            float t2, u, v;
+            if (ray_tri_uvt(op, od, p0, e1, e2, t2, u, v) && !(t2 > ot || t2 < 0.0f)) {
+              const unsigned long long kk =
+                  ANY ? (unsigned long long)p
+                      : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
+              if (kk < key) {
+                key = kk;
+                ku = u;
+                kv = v;
+                kt = t2;
+              }
+              return ANY;  // later triangles of this lane have higher indices
+            }
+            return false;
+          };
+          const uint32_t ocached = kLeafCacheWords16 != 0u ? geo_load4(geo, otbase + ostart * 48u + 44u) : 0u;
+          if (ocached != 0u) {
+            // the leaf is in LDS: three 16-bit vertex numbers per triangle, e1 and e2 rebuilt
+            // with the subtractions the upload does for DTri
+            const uint2 *rows = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(s_cache) + (ocached - 1u));
+            for (uint32_t k = lane; k < ocount; k += 64u) {
+              const uint32_t p = ostart + k;
+              if (p == oskip) continue;
+              const uint2 row = rows[k];
+              const uint4 q0 = s_cache[row.x & 0xFFFFu], q1 = s_cache[row.x >> 16], q2 = s_cache[row.y];
+              const v3 p0 = V3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+              const v3 p1 = V3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+              const v3 p2 = V3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+              if (consider(p, p0, sub3(p1, p0), sub3(p2, p0))) break;
+            }
+          } else {
+            uint32_t boff = geo_load4(geo, otbase + ostart * 48u + 28u) + lane * 16u;  // the leaf's scan blocks
+            for (uint32_t k = lane; k < ocount; k += 64u, boff += kScanBlockBytes) {
+              const uint32_t p = ostart + k;
+              if (p == oskip) continue;
+              const float4 a0 = geo_load16(geo, boff), a1 = geo_load16(geo, boff + 1024u);
+              const float a2 = __uint_as_float(geo_load4(geo, boff + 2048u - lane * 12u));
+              if (consider(p, V3(a0.x, a0.y, a0.z), V3(a0.w, a1.x, a1.y), V3(a1.z, a1.w, a2))) break;
+            }
+          }
+          unsigned long long wkey = key;
+          for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_xor(wkey, off);
+            wkey = other < wkey ? other : wkey;
+          }
+          const bool mine = (int)lane == owner;
+          if (wkey != ~0ull) {
+            const int winner = __ffsll((long long)__ballot(key == wkey)) - 1;
+            const float wu = __shfl(ku, winner), wv = __shfl(kv, winner), wt = __shfl(kt, winner);
+            const uint32_t wp = ANY ? (uint32_t)wkey : ~(uint32_t)wkey;
+            if (mine) accept(wt, wu, wv, wp);
+            if (COUNT && mine) {
+              // a scan tests every triangle (ANY: up to the first accepted one) except the excluded one
+              const uint32_t tested = ANY ? (wp - ostart + 1u) : ocount;
+              const bool skipped = oskip >= ostart && oskip < ostart + tested;
+              const uint32_t n_tested = tested - (skipped ? 1u : 0u);
+              lc.triangles += n_tested;
+              if (ocached != 0u) lc.tri_wave_lds += n_tested;
+              else lc.tri_wave_mem += n_tested;
+            }
+          } else if (COUNT && mine) {
+            const bool skipped = oskip >= ostart && oskip < ostart + ocount;
+            const uint32_t n_tested = ocount - (skipped ? 1u : 0u);
+            lc.triangles += n_tested;
+            if (ocached != 0u) lc.tri_wave_lds += n_tested;
+            else lc.tri_wave_mem += n_tested;
+          }
+          if (mine) {
+            leaf_count = 0u;
+            if ((fl & F_WRAP) == 0u) fl &= ~F_HOLD;
+          }
+        }
+        // 1/dir is not needed by the scan: rebuilding it here (same operation, same
+        // bits) instead of keeping it frees its registers for the scan
+        if (any_big) cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+        MIRT_PH_MARK(7);
+      }
+
+      // ------------------------------------------ small leaves, four lanes each
+      {
+        const bool waits = (fl & (F_WALK | F_HOLD | F_BLAS)) == (F_WALK | F_HOLD | F_BLAS) && leaf_count != 0u;
+        const unsigned long long smallmask = __ballot(waits);
+        if (smallmask != 0ull) {
+          const uint32_t n_wait = (uint32_t)__popcll(smallmask);
+          const uint32_t rank = trv_rank(smallmask);  // among the waiting lanes, in lane order
+          if (waits) own[rank] = lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t first_off = tbase + __umul24(leaf_start, 48u);  // byte offset of the leaf's first triangle
+          const uint32_t group = lane >> 2, quad = lane & 3u;
+          for (uint32_t round = 0; round * 16u < n_wait; ++round) {
+            const uint32_t r = round * 16u + group;
+            const bool serve = r < n_wait;
+            const int ol = serve ? (int)own[r] : (int)lane;  // the lane this group of four works for
+            const v3 op = V3(__shfl(cpos.x, ol), __shfl(cpos.y, ol), __shfl(cpos.z, ol));
+            const v3 od = V3(__shfl(cdir.x, ol), __shfl(cdir.y, ol), __shfl(cdir.z, ol));
+            const float ot = __shfl(t, ol);
+            const uint32_t ofirst = (uint32_t)__shfl((int)first_off, ol);
+            const uint32_t ostart = (uint32_t)__shfl((int)leaf_start, ol);
+            const uint32_t ocount_all = (uint32_t)__shfl((int)leaf_count, ol);  // pulled by every lane: a lane that sits out must still lend its registers
+            const uint32_t ocount = serve ? ocount_all : 0u;
+            const uint32_t oskip = (uint32_t)__shfl((int)excl_prim, ol);
+            // this lane's best over triangles quad, quad + 4, ... of the leaf
+            // key: ANY -> index (first accepted in index order);
+            //      else (t2 bits << 32) | ~index (smallest t2, ties to the highest index)
+            unsigned long long key = ~0ull;
+            float ku = 0.0f, kv = 0.0f, kt = 0.0f;
+            for (uint32_t i = quad; __ballot(i < ocount) != 0ull; i += 4u) {
+              if (i < ocount && ostart + i != oskip) {
+                const uint32_t toff = ofirst + __umul24(i, 48u);
+                const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+                float t2, u, v;
+                if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+                    !(t2 > ot || t2 < 0.0f)) {
+                  const uint32_t p = ostart + i;
+                  const unsigned long long kk =
+                      ANY ? (unsigned long long)p
+                          : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
+                  if (kk < key) {
+                    key = kk;
+                    ku = u;
+                    kv = v;
+                    kt = t2;
+                  }
+                }
+              }
+            }
+            // the four lanes of a group agree on the winner
+            for (int step = 0; step < 2; ++step) {
+              const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+              const uint32_t olo = step == 0 ? quad_xor1(klo) : quad_xor2(klo);
+              const uint32_t ohi = step == 0 ? quad_xor1(khi) : quad_xor2(khi);
+              const uint32_t ou = step == 0 ? quad_xor1(__float_as_uint(ku)) : quad_xor2(__float_as_uint(ku));
+              const uint32_t ov = step == 0 ? quad_xor1(__float_as_uint(kv)) : quad_xor2(__float_as_uint(kv));
+              const uint32_t otb = step == 0 ? quad_xor1(__float_as_uint(kt)) : quad_xor2(__float_as_uint(kt));
+              const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+              if (other < key) {
+                key = other;
+                ku = __uint_as_float(ou);
+                kv = __uint_as_float(ov);
+                kt = __uint_as_float(otb);
+              }
+            }
+            // ... and the owner pulls it from the first lane of its group
+            const bool mine = waits && rank >= round * 16u && rank < round * 16u + 16u;
+            const int from = mine ? (int)((rank - round * 16u) << 2) : (int)lane;
+            const uint32_t wlo = (uint32_t)__shfl((int)(uint32_t)key, from), whi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), from);
+            const float wu = __shfl(ku, from), wv = __shfl(kv, from), wt = __shfl(kt, from);
+            if (mine) {
+              const unsigned long long wkey = ((unsigned long long)whi << 32) | wlo;
+              const uint32_t wp = ANY ? wlo : ~wlo;
+              const bool won = wkey != ~0ull;
+              if (COUNT) {
+                // every triangle of the leaf is tested (ANY: up to the first accepted one) except the excluded one
+                const uint32_t tested = (ANY && won) ? (wp - leaf_start + 1u) : leaf_count;
+                const bool skipped = excl_prim >= leaf_start && excl_prim < leaf_start + tested;
+                lc.triangles += tested - (skipped ? 1u : 0u);
+              }
+              if (won) accept(wt, wu, wv, wp);
+              leaf_count = 0u;
+              if ((fl & F_WRAP) == 0u) fl &= ~F_HOLD;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+
+      // ---------------------------------------------------- housekeeping
+      // Held lanes with no triangle leaf left: a BLAS walk that is done goes back
+      // to the TLAS; a TLAS leaf becomes a slot range; the next instance of the
+      // range is entered (shaders/ray_extend.slang:190-203; matrices were built
+      // on the host); with nothing left the walk ends.
+      {
+        const bool hk = (fl & (F_WALK | F_HOLD)) == (F_WALK | F_HOLD);
+        if (__ballot(hk) != 0ull) {
+          if (hk) {
+            uint32_t slot_i = 0u, slot_end = 0u;
+            if ((fl & F_BLAS) != 0u) {
+              fl &= ~F_BLAS;
+              cpos = wpos;
+              cdir = wdir;
+              cdinv = V3(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // the bits the walk started with
+              cur = tlas_cur;
+              slot_i = slot_next;
+              slot_end = slot_stop;
+              nbase = tlas_nbase;
+              tseed = 0.0f;
+            } else {
+              if ((fl & F_WRAP) != 0u) fl |= F_TDONE;
+              if (leaf_count != 0u) {
+                slot_i = leaf_start;
+                slot_end = leaf_start + (leaf_count == kBigLeaf ? sc.tlas_big[leaf_start] : leaf_count);
+                leaf_count = 0u;
+              }
+            }
+            if (slot_i < slot_end) {
+              const uint32_t id = sc.tlas_to_inst[slot_i];
+              const DInst *inst = &sc.inst[id];
+              if (COUNT) lc.instance_visits++;
+              const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
+              const float4 m1 = reinterpret_cast<const float4 *>(inst->mi)[1];
+              const float4 m2 = reinterpret_cast<const float4 *>(inst->mi)[2];
+              tlas_cur = cur;
+              slot_next = slot_i + 1u;
+              slot_stop = slot_end;
+              cur_inst = id;
+              nbase = inst->node_base * 32u;
+              tbase = sc.tri_off + inst->tri_base * 48u;
+              const v3 pos = wpos, dir = wdir;  // the world-space ray
+              cpos = V3(__builtin_fmaf(m0.z, pos.z, __builtin_fmaf(m0.y, pos.y, m0.x * pos.x)) + m0.w,
+                        __builtin_fmaf(m1.z, pos.z, __builtin_fmaf(m1.y, pos.y, m1.x * pos.x)) + m1.w,
+                        __builtin_fmaf(m2.z, pos.z, __builtin_fmaf(m2.y, pos.y, m2.x * pos.x)) + m2.w);
+              cdir = V3(__builtin_fmaf(m0.z, dir.z, __builtin_fmaf(m0.y, dir.y, m0.x * dir.x)),
+                        __builtin_fmaf(m1.z, dir.z, __builtin_fmaf(m1.y, dir.y, m1.x * dir.x)),
+                        __builtin_fmaf(m2.z, dir.z, __builtin_fmaf(m2.y, dir.y, m2.x * dir.x)));
+              cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+              excl_prim = id == last_inst ? last_prim : kNoExclude;
+              cur = 0u;
+              tseed = -FLT_MAX;
+              fl = (fl | F_BLAS) & ~(F_WRAP | F_HOLD);
+            } else if ((fl & F_TDONE) != 0u) {
+              fl &= ~F_WALK;
+            } else {
+              fl &= ~(F_WRAP | F_HOLD);
+            }
+          }
+        }
+      }
+
+      // ---------------------------------------------------------- refill
+      {
+        const bool fin = (fl & (F_HAS | F_WALK)) == F_HAS;
+        if (__ballot(fin) != 0ull) {
+          BestHit best;
+          best.t = t;
+          best.u = best_u;
+          best.v = best_v;
+          best.prim = best_prim;
+          best.inst = best_inst;
+          finish(fin, payload, (fl & F_FOUND) != 0u, t, best);
+        }
+        if ((fl & F_WALK) == 0u) fl = 0u;
+        if (!exhausted && __popcll(__ballot((fl & F_WALK) != 0u)) < kRefillBelow) {
+          const unsigned long long need = __ballot((fl & F_HAS) == 0u);
+          if (chunk_next >= chunk_end) {
+            uint32_t cbase = 0;
+            if (lane == 0u) cbase = atomicAdd(ws.counter, kChunk);
+            cbase = (uint32_t)__shfl((int)cbase, 0);
+            chunk_next = cbase < ws.count ? cbase : ws.count;
+            chunk_end = cbase + kChunk < ws.count ? cbase + kChunk : ws.count;
+            if (chunk_next >= chunk_end) exhausted = true;
+          }
+          const uint32_t idx = chunk_next + trv_rank(need);
+          if ((fl & F_HAS) == 0u && idx < chunk_end) {
+            RayIn ray;
+            fetch(idx, ray);
+            // a negative tmax marks an entry that traces nothing
+            fl = (ray.tmax < 0.0f) ? F_HAS : (F_HAS | F_WALK);
+            t = ray.tmax;
+            wpos = cpos = ray.pos;
+            wdir = cdir = ray.dir;
+            cdinv = V3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+            last_inst = ray.last_inst;
+            last_prim = ray.last_prim;
+            payload = ray.payload;
+            cur = 0u;
+            nbase = tlas_nbase;
+            tseed = 0.0f;
+            leaf_count = 0u;
+          }
+          const uint32_t taken = (uint32_t)__popcll(need);
+          chunk_next = chunk_next + taken < chunk_end ? chunk_next + taken : chunk_end;
+        }
+        if (exhausted && __ballot((fl & F_HAS) != 0u) == 0ull) break;
+      }
+    }
+
+    // =============================================================== steps
+    // One node for every lane that can move (blasFirstHit / tlasFirstHit,
+    // shaders/ray_extend.slang:127-142, 173-188); a lane that hits a leaf, or whose tree is
+    // done, waits for the service point.
+#pragma unroll 1
+    for (int k = 0; k < kStepsPerCheck; ++k) {
+      const bool active = (fl & (F_WALK | F_HOLD)) == F_WALK;
+      if (__ballot(active) == 0ull) break;
+      MIRT_PH_COUNT(5);
+      MIRT_PH_ADD(6, __popcll(__ballot((fl & F_WALK) != 0u)));
+      MIRT_PH_ADD(1, __popcll(__ballot(active)));
+      if (active) {
+        const uint32_t off = nbase + (cur << 5);
+        const float4 a0 = geo_load16(geo, off), a1 = geo_load16(geo, off + 16u);
+        if (COUNT) {
+          if ((fl & F_BLAS) != 0u) lc.blas_nodes++;
+          else lc.tlas_nodes++;
+        }
+        const bool hit = ray_box(cpos, cdinv, a0, a1, tseed, t);
+        const uint32_t wa = __float_as_uint(a0.w), wb = __float_as_uint(a1.w);
+        const uint32_t leaf = wb >> 24;
+        const bool leaf_hit = hit && leaf != 0u;
+        cur = (hit && leaf == 0u) ? wa : (wb & kSkipMask);
+        leaf_start = wa;
+        leaf_count = leaf_hit ? leaf : 0u;  // kBigLeaf is resolved by whoever takes the leaf
+        const bool wrapped = cur == 0u;
+        fl = (fl & ~(F_WRAP | F_HOLD)) | (wrapped ? F_WRAP : 0u) | ((leaf_hit || wrapped) ? F_HOLD : 0u);
+      }
+    }
+  }
+  MIRT_PH_FLUSH(ws.phase);
+}
 
 // The record extensionMain stores for a hit (shaders/ray_extend.slang:86-89
 // and 204-207): barycentric position and normal of the winning triangle moved

@@ -106,8 +106,6 @@ inline dim3 stream_grid(const LaunchCfg &cfg, K kernel) {
 // Blocks of kEngineBlock threads that fill the device for the traversal engine
 // (resident blocks per CU from the occupancy query — one — times CUs).
 int trace_grid_blocks(int num_cus);
-// lanes of that grid: the walk's spill rows hold one stack entry per lane (DScene::stack_spill)
-size_t trace_grid_lanes(int num_cus);
 
 void launch_sample(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 // per-slot random streams: the same stage with the slots of the terminate queue taking sample numbers in ascending slot order
@@ -153,7 +151,6 @@ struct TlasResident {
   uint32_t capacity;   // nodes it has room for
   uint32_t *big;       // out-of-line leaf sizes, indexed by the leaf's first slot
   uint32_t *to_inst;   // instance of every slot
-  uint32_t max_height; // the tallest tree the scene's traversal stack has rows for
 };
 int build_tlas_device(hipStream_t stream, const float *geom_aabbs6, uint32_t n_geometries, const float *mats16,
                       const uint32_t *inst_geometry, uint32_t n_instances, MirtBVHNode *nodes_out, uint32_t nodes_capacity,

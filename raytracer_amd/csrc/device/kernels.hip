@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp)
 constexpr uint32_t kMissInst = 0xFFFFFFFFu;
 
 template <bool COUNT>
-__global__ __launch_bounds__(kEngineBlock) void k_extend(DScene sc, DState st, DFrameParams fp) {
+__global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void k_resolve(DState st, DFrameParams fp) {
 // ----------------------------------------------------------------- trace
 
 template <bool ANY, bool COUNT>
-__global__ __launch_bounds__(kEngineBlock) void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
+__global__ MIRT_ENGINE_BOUNDS void k_trace(DScene sc, const DRay *rays, const float *tmax, uint32_t n,
                                                MirtHitId *out, unsigned long long *counts5, uint32_t *work) {
   LaneCounts lc;
   auto fetch = [&](uint32_t idx, RayIn &r) {
@@ -918,8 +918,6 @@ int trace_grid_blocks(int num_cus) {
   }
   return it->second * num_cus;
 }
-
-size_t trace_grid_lanes(int num_cus) { return (size_t)trace_grid_blocks(num_cus) * kEngineBlock; }
 
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));

@@ -81,14 +81,6 @@ constexpr uint32_t kScanBlockBytes = 2304u;
 constexpr uint32_t kLeafCacheBytes = MIRT_LEAF_CACHE_KB * 1024u;
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
 
-// The walk keeps the deferred right children of a lane on a stack: the first kStackLds entries in
-// LDS, deeper ones in spill rows in memory (DScene::stack_spill), row r holding entry kStackLds + r
-// of every lane of the traversal grid.
-#ifndef MIRT_STACK_LDS
-#define MIRT_STACK_LDS 10u
-#endif
-constexpr uint32_t kStackLds = MIRT_STACK_LDS;
-
 struct DTriN {
   float n0[4], n1[4], n2[4];
 };
@@ -160,8 +152,6 @@ struct DScene {
   const DTriN *trin;
   const uint4 *leaf_cache;    // image of the LDS leaf cache (see kLeafCacheBytes)
   uint32_t leaf_cache_bytes;  // multiple of 16, 0 when no leaf is cached
-  unsigned char *stack_spill; // spill rows of the walk's stack (see kStackLds); null when no walk can get that deep
-  uint32_t stack_spill_bytes;
   const DMaterial *mat;
   const uint32_t *lights;     // instance ids
   uint32_t n_lights;          // 0 when the scene has none

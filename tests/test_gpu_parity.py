@@ -773,6 +773,39 @@ def test_whole_wave_leaves_of_every_block_shape(pt):
     assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
 
 
+def test_small_leaves_of_every_size_tested_four_lanes_to_a_leaf(pt):
+    """Leaves below the whole-wave threshold are tested at the service point, four lanes to a leaf
+    and sixteen leaves per pass: every size 1..23 (one to six passes of a lane over its leaf), far
+    more leaves than one pass takes, closest and any hit with visit counts, and bounce rays whose
+    excluded triangle sits inside such a leaf."""
+    rng = np.random.default_rng(23)
+    sizes = [int(n) for n in rng.permutation(np.repeat(np.arange(1, 24), 3))]
+    arrays = _comb_scene(sizes, 12)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    rays = random_rays(40009, 29, centre=(0.0, 0.0, 3.0), spread=2.0)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want) and gc.as_dict() == wc.as_dict()
+    hit = want["instance_id"] != ffi.NO_HIT
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    leaf_of = np.searchsorted(starts, want["triangle_id"][hit], side="right") - 1
+    assert {sizes[i] for i in set(leaf_of.tolist())} == set(range(1, 24))
+    tmax = np.full(len(rays), 2.0, "<f4")
+    want_any, wca = sc.trace_any(rays, tmax, True)
+    got_any, gca = pt.trace_any(rays, tmax, True)
+    assert hits_equal(got_any, want_any) and gca.as_dict() == wca.as_dict()
+    W, H = 64, 48
+    src = host.make_sample_sources(W, H, 8)
+    cam = host.default_camera(W, H)
+    pt.create_state(W, H, 1000, src, pathtracer.default_params(max_bounces=4, seed=8))
+    pt.set_camera(cam)
+    pt.render_spp(3)
+    s4, cnt = pt.read_accum()
+    w4, wcnt, _ = sc.render(cam, src, W, H, po.default_params(max_bounces=4, seed=8), 0, 3)
+    assert np.array_equal(s4, w4) and np.array_equal(cnt, wcnt)
+
+
 def test_group_of_contexts_splits_samples_and_reduces_bit_exactly(config_scenes):
     """mirt_group_*: three contexts (all on device 0 here; one per GPU on a node), samples
     split 2 + 2 + 1 and then 2 + 1 + 1, integer reduction into member 0 — the same sums as

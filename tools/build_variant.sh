@@ -1,12 +1,17 @@
 #!/bin/bash
-# Build a variant of libmirt.so with extra compiler flags: tools/build_variant.sh <name> <flags...>
-# -> raytracer_amd/lib/libmirt_<name>.so (select it with MIRT_DEVICE_LIB=libmirt_<name>.so)
-set -e
+# Builds the device library with extra -D definitions into raytracer_amd/lib/libmirt_<name>.so
+# (selected at run time with MIRT_DEVICE_LIB=libmirt_<name>.so).  Usage: tools/build_variant.sh <name> -DA=1 -DB=2 ...
+set -eu
 name=$1; shift
-mkdir -p build/variant_$name
-for f in raytracer_amd/csrc/device/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Iinclude "$@" -c $f -o build/variant_$name/$(basename $f .hip).o &
+out=build/variants/$name
+mkdir -p "$out"
+objs=""
+for src in raytracer_amd/csrc/device/*.hip; do
+  o=$out/$(basename "${src%.hip}").o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+    -fno-gpu-rdc -Wall -Iinclude "$@" -c "$src" -o "$o" &
+  objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o raytracer_amd/lib/libmirt_$name.so build/variant_$name/*.o
-echo built raytracer_amd/lib/libmirt_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o raytracer_amd/lib/libmirt_$name.so $objs
+echo "built raytracer_amd/lib/libmirt_$name.so"
