@@ -47,6 +47,28 @@ int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char
  * RGBA8 texels, MIRT_FILTER_*.  Returns its 1-based id (0 in a material means
  * none).  The reference has the ids and no texture store (src/material.rs:15-18). */
 int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter);
+/* The same from a PNG image in memory (8 or 16 bits per channel, any colour type, not
+ * interlaced; rows top to bottom, so v = 0 is the top row as in glTF). */
+int mirth_add_texture_png(mirth_scene *s, const void *png, size_t len, uint32_t filter);
+
+/* What mirth_load_gltf did with the file. */
+typedef struct MirthGltfInfo {
+  uint32_t n_meshes;              /* meshes added to the MeshServer (a primitive shared by several nodes counts once) */
+  uint32_t n_instances;           /* entities spawned */
+  uint32_t n_materials;           /* materials added */
+  uint32_t n_textures;            /* images decoded into the texture store */
+  uint32_t n_baked;               /* instances whose sheared world matrix was applied to a copy of the mesh */
+  uint32_t n_skipped_primitives;  /* not TRIANGLES, no POSITION, morph targets, or unreadable accessors */
+  uint32_t n_skipped_images;      /* not PNG, interlaced, or unreadable */
+  uint32_t reserved;
+} MirthGltfInfo;
+/* A glTF 2.0 scene (.gltf with external or base64 buffers, or .glb): every triangle primitive the
+ * default scene's nodes refer to becomes a mesh (positions as in the file, no normalisation), every
+ * reference to it an entity with the node's world transform and the primitive's material, PNG
+ * base-colour and emissive textures go to the texture store.  Finishes the loader the reference
+ * leaves commented out (src/scenes.rs:332-399).  Returns the number of entities spawned, or -1
+ * (mirth_last_error says why).  `info` may be NULL. */
+int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info);
 /* Vertex uvs of a loaded mesh from two of its normalised position axes:
  * uv = position[axis] * scale + offset.  (The reference uploads uv = 0 for
  * every vertex, src/mesh.rs:241; so does this library until this is called.) */

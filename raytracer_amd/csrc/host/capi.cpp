@@ -224,6 +224,24 @@ int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uin
   return (int)s->scene.textures.size();  // 1-based: 0 means "no texture" in a material
 }
 
+int mirth_add_texture_png(mirth_scene *s, const void *png, size_t len, uint32_t filter) {
+  if (!s || !png || filter > MIRT_FILTER_BILINEAR) return -1;
+  uint32_t w = 0, h = 0;
+  std::vector<uint32_t> texels;
+  if (!decode_png_rgba8(static_cast<const unsigned char *>(png), len, w, h, texels, s->error)) return -1;
+  return mirth_add_texture(s, w, h, texels.data(), filter);
+}
+
+int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info) {
+  if (!s || !path) return -1;
+  MirthGltfInfo local;
+  memset(&local, 0, sizeof(local));
+  if (!load_gltf(s->scene, path, local, s->error)) return -1;
+  s->bound = false;
+  if (info) *info = local;
+  return (int)local.n_instances;
+}
+
 int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v, float scale, float offset) {
   if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size() || axis_u < 0 || axis_u > 2 || axis_v < 0 || axis_v > 2)
     return -1;

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mirt.h"
+#include "mirt_host.h"
 
 namespace mirth {
 
@@ -176,6 +177,12 @@ struct Scene {
   void bind();               // src/binder.rs:184-282
   void fill_desc(MirtSceneDesc &d) const;
 };
+
+// gltf.cpp: a glTF 2.0 file into meshes, materials, textures and entities of `scene`
+bool load_gltf(Scene &scene, const std::string &path, MirthGltfInfo &info, std::string &err);
+// PNG bytes -> RGBA8 texels (red in the low byte), rows top to bottom
+bool decode_png_rgba8(const unsigned char *png, size_t len, uint32_t &width, uint32_t &height,
+                      std::vector<uint32_t> &texels, std::string &err);
 
 MirtMaterial default_material();  // src/material.rs:27-42
 MirtCamera default_camera();      // src/camera.rs:117-128

@@ -36,6 +36,8 @@ DielectricData = np.dtype([("albedo", "<f4", 4), ("ir", "<f4"), ("pad", "<u4", 3
 EmissiveData = np.dtype([("albedo", "<f4", 4)])
 ClassicMaterialRef = np.dtype([("kind", "<u4"), ("data", "<u4")])
 Texture = np.dtype([("width", "<u4"), ("height", "<u4"), ("first_texel", "<u4"), ("filter", "<u4")])
+GltfInfo = np.dtype([("n_meshes", "<u4"), ("n_instances", "<u4"), ("n_materials", "<u4"), ("n_textures", "<u4"),
+                     ("n_baked", "<u4"), ("n_skipped_primitives", "<u4"), ("n_skipped_images", "<u4"), ("reserved", "<u4")])
 FILTER_NEAREST, FILTER_BILINEAR = 0, 1
 Ray = np.dtype([("pos", "<f4", 3), ("dir", "<f4", 3), ("last_inst", "<u4"), ("last_prim", "<u4")])
 HitId = np.dtype([("instance_id", "<u4"), ("triangle_id", "<u4"), ("t", "<f4"), ("front_face", "<u4")])
@@ -204,6 +206,8 @@ def host_lib():
         L.mirth_set_dragon_standin.argtypes = [vp, i32, u32]
         L.mirth_add_texture.argtypes = [vp, u32, u32, vp, u32]
         L.mirth_mesh_set_planar_uv.argtypes = [vp, i32, i32, i32, C.c_float, C.c_float]
+        L.mirth_add_texture_png.argtypes = [vp, vp, C.c_size_t, u32]
+        L.mirth_load_gltf.argtypes = [vp, C.c_char_p, vp]
         L.mirth_det_sincos.restype = None
         L.mirth_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mirth_add_material.argtypes = [vp, vp]

@@ -86,6 +86,10 @@ def build_blas(positions4, faces4):
     return faces, nodes[:n.value].copy()
 
 
+class HostError(RuntimeError):
+    """A call into libmirt_host.so failed; the message is mirth_last_error's."""
+
+
 class Scene:
     """MeshServer + MaterialServer + entity list + binder."""
 
@@ -109,7 +113,7 @@ class Scene:
 
     def _check(self, rc, what):
         if rc < 0:
-            raise RuntimeError(f"{what}: {self._L.mirth_last_error(self._h).decode()}")
+            raise HostError(f"{what}: {self._L.mirth_last_error(self._h).decode()}")
         return rc
 
     def set_blas_builder(self, pathtracer):
@@ -170,6 +174,18 @@ class Scene:
         t = np.ascontiguousarray(rgba8, "<u4")
         h, w = t.shape
         return self._check(self._L.mirth_add_texture(self._h, w, h, t.ctypes.data, filter), "add_texture")
+
+    def add_texture_png(self, png_bytes, filter=ffi.FILTER_BILINEAR):
+        """A PNG image in memory; returns the 1-based texture id."""
+        buf = C.create_string_buffer(bytes(png_bytes), len(png_bytes))
+        return self._check(self._L.mirth_add_texture_png(self._h, buf, len(png_bytes), filter), "add_texture_png")
+
+    def load_gltf(self, path):
+        """Every triangle primitive of a glTF 2.0 scene (.gltf / .glb) as meshes, entities, materials and
+        textures; returns what was done as a dict (n_meshes, n_instances, ...)."""
+        info = np.zeros(1, ffi.GltfInfo)
+        self._check(self._L.mirth_load_gltf(self._h, path.encode(), info.ctypes.data), "load_gltf")
+        return {k: int(info[0][k]) for k in info.dtype.names if k != "reserved"}
 
     def set_planar_uv(self, mesh_id, axis_u=0, axis_v=1, scale=0.5, offset=0.5):
         """uv = position[axis] * scale + offset for every vertex of a loaded mesh."""
