@@ -203,7 +203,8 @@ void instance_matrices(const MirtTransform &t, float M[12], float Mi[12]) {
 }
 
 // fn(i) for i in [0, n) on up to sixteen host threads (the instance matrices: six sin / cos and
-// four 4x4 products each; 200 000 instances take 15 ms on one core).  fn must not throw.
+// four 4x4 products each; 200 000 instances take 15 ms on one core).  fn must not throw and must
+// touch only element i.
 template <class F>
 void parallel_for(uint32_t n, F fn) {
   unsigned workers = std::thread::hardware_concurrency();
@@ -217,9 +218,13 @@ void parallel_for(uint32_t n, F fn) {
   for (unsigned w = 0; w < workers; ++w) {
     const uint32_t lo = w * chunk, hi = lo + chunk < n ? lo + chunk : n;
     if (lo >= hi) break;
-    pool.emplace_back([=]() {
+    try {
+      pool.emplace_back([=]() {
+        for (uint32_t i = lo; i < hi; ++i) fn(i);
+      });
+    } catch (...) {  // no more threads to be had: this one does the slice itself
       for (uint32_t i = lo; i < hi; ++i) fn(i);
-    });
+    }
   }
   for (std::thread &t : pool) t.join();
 }

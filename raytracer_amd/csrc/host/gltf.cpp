@@ -622,19 +622,25 @@ bool read_accessor(Doc &d, long index, int want_comp, bool as_index, std::vector
   count = (size_t)cnt;
   if (as_index && !(ct == 5121 || ct == 5123 || ct == 5125)) { d.err = "index accessor must be unsigned"; return false; }
   const long bv = a->index("bufferView");
+  const unsigned char *p = nullptr;
+  size_t len = 0, stride = 0;
+  const size_t elem = cb * (size_t)comp;
+  const double off = a->number("byteOffset", 0.0);
+  if (bv >= 0) {
+    // the accessor must lie inside its view before anything is sized by its count
+    if (!d.view(bv, p, len, stride)) return false;
+    if (stride == 0) stride = elem;
+    if (off < 0 || (count > 0 && off + (double)(count - 1) * (double)stride + (double)elem > (double)len)) {
+      d.err = "accessor runs past its bufferView";
+      return false;
+    }
+  } else if (count > ((size_t)1 << 26)) {
+    d.err = "accessor without a bufferView is too large";
+    return false;
+  }
   if (f) f->assign(count * (size_t)comp, 0.0f);
   if (u) u->assign(count * (size_t)comp, 0u);
   if (bv < 0) return true;  // all zeros
-  const unsigned char *p;
-  size_t len, stride;
-  if (!d.view(bv, p, len, stride)) return false;
-  const size_t elem = cb * (size_t)comp;
-  if (stride == 0) stride = elem;
-  const double off = a->number("byteOffset", 0.0);
-  if (off < 0 || (count > 0 && off + (double)(count - 1) * (double)stride + (double)elem > (double)len)) {
-    d.err = "accessor runs past its bufferView";
-    return false;
-  }
   const Json *nrm = a->get("normalized");
   const bool normalized = nrm && nrm->kind == Json::Bool && nrm->b;
   for (size_t i = 0; i < count; ++i) {
