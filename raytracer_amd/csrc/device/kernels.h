@@ -72,7 +72,10 @@ struct DFrameParams {
 };
 
 // Threads per block of the streaming frame kernels (see block_push2).
-constexpr unsigned kStreamBlock = 1024;
+#ifndef MIRT_STREAM_BLOCK
+#define MIRT_STREAM_BLOCK 1024
+#endif
+constexpr unsigned kStreamBlock = MIRT_STREAM_BLOCK;
 
 struct LaunchCfg {
   hipStream_t stream;

@@ -661,8 +661,11 @@ __device__ __forceinline__ bool shade_uber_slot(const DScene &sc, v3 wo, v3 hit_
 #ifndef MIRT_SHADE_WAVES
 #define MIRT_SHADE_WAVES 4
 #endif
+#ifndef MIRT_SHADE_ATTR
+#define MIRT_SHADE_ATTR
+#endif
 template <bool RESPAWN>
-__global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
+__global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR void k_finish_shade_uber(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   __shared__ BlockReserve shr;
   const uint32_t par = fp.frame & 1u;
