@@ -182,10 +182,10 @@ struct WorkSource {
 #define MIRT_ENGINE_BLOCK 1024u
 #endif
 // Threads per block of every kernel built on the engine.  One 1024-thread block
-// per CU (four waves per SIMD): the per-thread state takes 80 KB of LDS and the
-// leaf cache, which every wave of the CU shares, up to 64 KB more.
+// per CU (four waves per SIMD, which is what 97 registers per lane allow): every
+// wave of the CU shares one copy of the leaf cache, up to 64 KB of LDS.
 constexpr uint32_t kEngineBlock = MIRT_ENGINE_BLOCK;
-// the leaf cache needs the one-block-per-CU shape; smaller blocks go without
+// blocks below 512 threads would need a copy of the leaf cache each and go without
 constexpr uint32_t kLeafCacheWords16 = kEngineBlock >= 512u ? kLeafCacheBytes / 16u : 0u;
 // resident waves per SIMD the engine kernels are compiled for (bounds their registers)
 #ifndef MIRT_ENGINE_WAVES_PER_SIMD
@@ -236,18 +236,23 @@ __device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
 // ALL lanes at every refill point, with fin = true on the lanes whose ray is
 // done, so it may use wave-aggregated pushes.
 //
-// The kernels built on it are bound by instruction issue, and lanes of a wave are on nodes
-// and on triangles in a ratio of about five to one: a step that serves both kinds runs the
-// triangle test for a handful of lanes.  So the step loop here only walks nodes (one 32-byte
-// fetch, one box test per lane and step), and a lane that hits a leaf waits for the service
-// point, entered when a quarter of the walking lanes wait.  There
+// Scheduling.  Lanes of a wave are on nodes and on triangles in a ratio of about five to one: a
+// step that served both kinds would run the triangle test for a handful of lanes.  So the step
+// loop only walks nodes (one 32-byte fetch, one box test per lane and step), and a lane that
+// hits a leaf waits for the service point, entered when a quarter of the walking lanes wait
+// (or none can move, or the wave is running low on rays; the condition is looked at every
+// kStepsPerCheck steps).  There
 //   - leaves of kCoopLeaf triangles or more are scanned by the whole wave, 64 per pass;
 //   - the small leaves (the builder's leaves hold up to four triangles, its bail-outs more)
 //     are tested four lanes to a leaf, sixteen leaves per pass: each lane takes every fourth
 //     triangle with the owner's ray (pulled across lanes), the four reduce to the winner —
 //     smallest t2, among equal t2 the highest index, which is what the shader's sequential
 //     scan with `t2 <= t` ends on — and the owner pulls it back;
-//   - housekeeping, hand-over of finished rays and refill follow as in the plain walk.
+//   - what happens once per instance or per ray follows for all waiting lanes at once: leaving
+//     a BLAS, turning a TLAS leaf into a slot range, entering the next instance, ending the
+//     walk, handing finished rays over and fetching new ones.
+// Nodes of all trees and all triangles live in one buffer addressed by 32-bit byte offsets into
+// one buffer descriptor; TLAS and BLAS nodes differ only in the lane's base and ray registers.
 // Everything a lane keeps per ray lives in registers; LDS holds the leaf cache and a
 // 64-entry list per wave.
 template <bool ANY, bool COUNT, class Fetch, class Finish>
