@@ -103,13 +103,17 @@ DEVICE_SOURCES = ["engine.h", "kernels.hip", "kernels.h", "layout.h", "device_ut
 
 
 def device_sources_sha():
-    """Hash of the sources the traversal and frame kernels are built from: a counter figure
-    taken from profiles/ is only used when it was measured on these very sources."""
+    """Hash of the sources the traversal and frame kernels are built from, comments and blank lines
+    left out: a counter figure taken from profiles/ is only used when it was measured on this very code."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in DEVICE_SOURCES:
-        with open(os.path.join(ROOT, "raytracer_amd", "csrc", "device", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", "device", name), "r") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        lines = [re.sub(r"//.*$", "", line).rstrip() for line in text.split("\n")]
+        h.update("\n".join(line for line in lines if line.strip()).encode())
     return h.hexdigest()[:16]
 
 
