@@ -69,7 +69,72 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--group", action="store_true",
+                    help="with --gpus N: one process driving N GPUs through mirt_group_* (PathtracerGroup) instead "
+                         "of N processes and an RCCL all-reduce")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="exercise the multi-process launcher only: every rank prints its rank environment and exits "
+                         "(no GPU, no torch)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second geometry's short run that the default one-GPU line carries as `secondary`")
     return ap.parse_args()
+
+
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: this process — which has not imported torch
+    or touched HIP, and never will — starts N fresh copies of itself, one per GPU, with the rank environment
+    torch.distributed.run would give them, forwards rank 0's JSON line and returns non-zero if any rank did.
+    Children are new processes (no exec of a process that has initialised the GPU)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, LOCAL_WORLD_SIZE=str(n))
+        # rank 0's stdout carries the line; the other ranks print nothing there, and every rank's stderr passes through
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves the others waiting in a collective: end them (by their own pids) instead of hanging
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
@@ -152,25 +217,37 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
     traffic = traffic_src = fabric_frac = None
     try:
         tj = json.load(open(args.traffic_json))
-        if (tj.get("workload") == workload and tj.get("paths_in_flight") == n_paths
-                and tj.get("device_sources_sha") == device_sources_sha()):
-            traffic = tj.get("memory_side_bytes_per_extend_launch")
-            traffic_src = {k: tj.get(k) for k in ("measured_at_head", "fetch_size_bytes", "write_size_bytes",
-                                                  "fetch_calibration")}
+        entries = tj.get("entries", [tj])
+        sha = device_sources_sha()
+        same = [e for e in entries if e.get("workload") == workload and e.get("paths_in_flight") == n_paths]
+        hit = [e for e in same if e.get("device_sources_sha") == sha]
+        if hit:
+            e = hit[0]
+            traffic = e.get("memory_side_bytes_per_extend_launch")
+            traffic_src = {k: e.get(k) for k in ("measured_at_head", "fetch_size_bytes", "write_size_bytes",
+                                                 "fetch_calibration")}
+            traffic_note = "counter passes taken on these very device sources"
             if gather_mall > 0 and ext_s > 0:
-                fabric_frac = tj["fetch_size_bytes"] / 64.0 / ext_s / gather_mall
-    except Exception:
+                fabric_frac = e["fetch_size_bytes"] / 64.0 / ext_s / gather_mall
+        elif same:
+            traffic_note = (f"not reported: {os.path.basename(args.traffic_json)} was measured on device sources "
+                            f"{same[0].get('device_sources_sha')}, this build is {sha} — run tools/traffic_pass.sh again")
+        else:
+            traffic_note = f"not reported: {os.path.basename(args.traffic_json)} holds no counter pass for '{workload}'"
+    except Exception as e:  # noqa: BLE001 - the line says why the figure is missing
         traffic = None
+        traffic_note = f"not reported: {type(e).__name__}: {e}"
     per_ray = {"tlas_nodes": c.tlas_nodes / max(c.rays, 1), "instance_visits": c.instance_visits / max(c.rays, 1),
                "blas_nodes": c.blas_nodes / max(c.rays, 1), "triangles": c.triangles / max(c.rays, 1),
                "triangles_fetched_by_a_lane": tri_lane / max(c.rays, 1),
                "triangles_in_whole_wave_scans_from_lds": tri_lds / max(c.rays, 1),
                "triangles_in_whole_wave_scans_from_memory": tri_scan / max(c.rays, 1)}
     return {
-        "bound": "hbm", "kernel": "k_extend", "unit": "GB/s",
+        "bound": "l1_gather", "kernel": "k_extend", "unit": "GB/s",
         "binding_resource": "per-lane dependent gathers: L1 / texture-address path first, L2-miss path second "
                             "(the scene is resident in L2 + Infinity Cache; HBM itself is nearly idle)",
         "achieved": achieved, "peak": peak, "frac": achieved / peak if peak > 0 else None,
+        "frac_source": "mirt_bench_gather",
         "peak_source": f"mirt_bench_gather in this process: {gather_l2 / 1e9:.1f} G lane-steps/s x 32 B from a 2 MiB table",
         "fabric_frac": fabric_frac,
         "gather_lane_steps_per_s": {"2MiB_table": gather_l2, "192MiB_table": gather_mall,
@@ -179,7 +256,7 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
         "lds_served_triangle_tests_per_launch": tri_lds / launches,
         "lds_served_bytes_equivalent_per_launch": 48 * tri_lds / launches,
         "launch_ms": ext_s * 1e3, "launches": launches,
-        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
         "hbm_peak": HBM_PEAK_GBS,
         "hbm_frac": (traffic / ext_s / 1e9 / HBM_PEAK_GBS) if traffic and ext_s > 0 else None,
         # the traffic model in the reference's struct sizes (64 B per node, 160 B per triangle test, 76 B per
@@ -254,13 +331,181 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
     print(json.dumps(out), flush=True)
 
 
+def build_workload(args, geometry):
+    """Scene buffers, sample sources, camera and parameters of the configuration being measured."""
+    from raytracer_amd import host, pathtracer
+    arrays, info = host.build_config_scene(args.config, standin=geometry)
+    W = args.width or info.width
+    H = args.height or info.height
+    if args.mode == "step":
+        W, H = args.width or 512, args.height or 512
+    src = host.make_sample_sources(W, H, info.seed, shuffle=2)
+    cam = host.default_camera(W, H)
+    params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
+                                       nee=info.nee)
+    return arrays, info, W, H, src, cam, params
+
+
+def timed_render(pt, steps, warmup, spp_step, first_sample, before=None, after=None):
+    """`warmup` untimed and `steps` timed mirt_render_spp(spp_step) passes on one context; `before` runs between
+    the two (barrier), `after` inside the timed region behind the last pass (the reduction).  Returns
+    (seconds, stats, whatever `after` returned)."""
+    pt.set_sample_range(first_sample)
+    for _ in range(warmup):
+        pt.render_spp(spp_step)
+    pt.synchronize()
+    pt.stats_reset()
+    pt.set_event_timing(True)
+    if before:
+        before()
+    pt.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pt.render_spp(spp_step)
+    pt.synchronize()
+    extra = after() if after else None
+    elapsed = time.perf_counter() - t0
+    pt.set_event_timing(False)
+    return elapsed, pt.stats(), extra
+
+
+def replay_counts(pt, ranges):
+    """Visit counts of the timed samples: the same sample numbers rendered again, untimed, with the counting
+    build of the traversal kernel."""
+    pt.stats_reset()
+    pt.set_counting(True)
+    for first, n in ranges:
+        pt.set_sample_range(first)
+        pt.render_spp(n)
+    pt.set_counting(False)
+    return pt.stats()
+
+
+def workload_name(args, W, H, geometry):
+    return f"config{args.config} {W}x{H}" + ("" if geometry == "knot" else f" {geometry}")
+
+
+def secondary_line(args, local_rank):
+    """The headline configuration on the second stand-in geometry (no pathological 2 888-triangle leaf), two
+    steps after one warm-up, with its own roofline block: a second driver-visible figure beside the knot's."""
+    from raytracer_amd import pathtracer
+    geometry = "suzanne"
+    arrays, info, W, H, src, cam, params = build_workload(args, geometry)
+    n_paths = W * H * args.paths_per_pixel
+    with pathtracer.Pathtracer(local_rank) as pt:
+        pt.upload_scene(arrays)
+        pt.create_state(W, H, n_paths, src, params)
+        pt.set_camera(cam)
+        steps, warmup, spp_step = 2, 1, args.spp_per_step
+        elapsed, st, _ = timed_render(pt, steps, warmup, spp_step, 0)
+        cst = replay_counts(pt, [(warmup * spp_step, steps * spp_step)])
+        assert cst.extend_counts.rays == st.extend_rays
+        rays = int(st.extend_rays + st.connect_rays)
+        roof = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, geometry), n_paths)
+    keep = ("bound", "kernel", "unit", "achieved", "peak", "frac", "frac_source", "fabric_frac", "hbm_frac", "traffic",
+            "traffic_note", "launch_ms", "launches", "per_ray")
+    return {"metric": "Mrays/s (extend+shadow), dragon 1080p", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, {info.max_bounces} bounces, "
+                                   f"{spp_step} spp per step, uber shading",
+                       "geometry": GEOMETRY[info.procedural_dragon], "paths_in_flight": n_paths},
+            "roofline": {k: roof.get(k) for k in keep}}
+
+
+def group_mode(args):
+    """One process, N GPUs: the same workload through mirt_group_* (PathtracerGroup) — scene, state and camera
+    replicated, every render call's samples split over the members on one host thread each, accumulators added
+    into member 0 by peer copies inside the timed region.  Weak scaling: spp_per_step samples per member and step."""
+    from raytracer_amd import pathtracer
+    n = args.gpus
+    arrays, info, W, H, src, cam, params = build_workload(args, args.geometry)
+    n_paths = W * H * args.paths_per_pixel
+    spp_step = args.spp_per_step
+    with pathtracer.PathtracerGroup(list(range(n))) as grp:
+        grp.upload_scene(arrays)
+        grp.create_state(W, H, n_paths, src, params)
+        grp.set_camera(cam)
+        for _ in range(args.warmup):
+            grp.render_spp(spp_step * n)
+        grp.reduce()
+        for m in grp.members:
+            m.synchronize()
+            m.stats_reset()
+            m.set_event_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            grp.render_spp(spp_step * n)
+        t1 = time.perf_counter()
+        grp.reduce()
+        elapsed = time.perf_counter() - t0
+        reduce_s = time.perf_counter() - t1
+        stats = []
+        for m in grp.members:
+            m.set_event_timing(False)
+            stats.append(m.stats())
+        rays = sum(int(s.extend_rays + s.connect_rays) for s in stats)
+        samples = sum(int(s.finished_samples) for s in stats)
+        per_member = [int(s.extend_rays + s.connect_rays) / elapsed / 1e6 for s in stats]
+        # member 0 took the first spp_step sample numbers of every call
+        m0 = grp.members[0]
+        cst = replay_counts(m0, [((args.warmup + k) * spp_step * n, spp_step) for k in range(args.steps)])
+        assert cst.extend_counts.rays == stats[0].extend_rays, (cst.extend_counts.rays, stats[0].extend_rays)
+        roofline = extend_roofline(m0, stats[0], cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths)
+        st = stats[0]
+    out = result_line(args, info, W, H, n_paths, n, elapsed, rays, samples, reduce_s, st, roofline, None,
+                      per_member, f"spp split x{n}, one process (mirt_group), peer-copy reduce to member 0")
+    print(json.dumps(out), flush=True)
+
+
+def result_line(args, info, W, H, n_paths, world, elapsed, rays, samples, reduce_s, st, roofline, cpu, per_rank,
+                parallelism):
+    geometry = GEOMETRY[info.procedural_dragon] if args.config >= 3 else "the reference's own assets (suzanne / teapot)"
+    return {
+        "metric": "Mrays/s (extend+shadow), dragon 1080p",
+        "value": rays / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, "
+                               f"{info.max_bounces} bounces, {args.spp_per_step} spp per step per GPU, "
+                               f"{'per-material' if info.shade_mode else 'uber'} shading",
+                   "geometry": geometry, "paths_in_flight": n_paths, "parallelism": parallelism},
+        "spp_per_s": samples / (W * H) / elapsed,
+        "rays": rays,
+        "reduce_ms": reduce_s * 1e3,
+        "per_rank_mrays_per_s": {"min": min(per_rank), "max": max(per_rank)},
+        "kernel_ms": {"extend": st.extend_ms, "extend_finish": st.finish_ms, "shade": st.shade_ms,
+                      "sample": st.sample_ms, "connect": st.connect_ms},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.group:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "pid": os.getpid(), "gpus": args.gpus,
+                          **{k: os.environ.get(k) for k in RANK_ENV}}), flush=True)
+        if os.environ.get("MIRT_BENCH_DRY_FAIL_RANK") == str(rank):  # lets a test see the launcher report a dead rank
+            sys.exit(3)
+        return
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.group and args.gpus > 1 and world == 1:
+        group_mode(args)
+        return
     dist = None
     import torch
     # MIRT_BENCH_DIST=1 takes the collective path with a single rank too (a rehearsal
@@ -273,19 +518,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
 
-    from raytracer_amd import distributed, host, pathtracer
+    from raytracer_amd import distributed, pathtracer
 
-    arrays, info = host.build_config_scene(args.config, standin=args.geometry)
-    W = args.width or info.width
-    H = args.height or info.height
-    src = host.make_sample_sources(W, H, info.seed, shuffle=2)
-    cam = host.default_camera(W, H)
-    params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
-                                       nee=info.nee)
-    if args.mode == "step":
-        W, H = args.width or 512, args.height or 512
-        src = host.make_sample_sources(W, H, info.seed, shuffle=2)
-        cam = host.default_camera(W, H)
+    arrays, info, W, H, src, cam, params = build_workload(args, args.geometry)
     pt = pathtracer.Pathtracer(local_rank)
     pt.upload_scene(arrays)
     if args.mode == "step":
@@ -300,37 +535,31 @@ def main():
     total_steps = args.warmup + args.steps
     # rank r owns sample numbers [r * total, (r + 1) * total) * spp_step
     first = rank * total_steps * spp_step
-    pt.set_sample_range(first)
-    for _ in range(args.warmup):
-        pt.render_spp(spp_step)
-    pt.synchronize()
-    if dist is not None:
-        # warm the collective too
-        distributed.reduce_device_accumulators(pt, device)
-    pt.stats_reset()
-    pt.set_event_timing(True)
 
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    pt.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pt.render_spp(spp_step)
-    pt.synchronize()
-    reduce_s = 0.0
-    if dist is not None:
-        reduce_s = distributed.reduce_device_accumulators(pt, device)
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    pt.set_event_timing(False)
-    st = pt.stats()
+    def before():
+        if dist is not None:
+            # warm the collective too (its result is discarded: the accumulators are reloaded with the sum of
+            # all ranks' warm-up samples, which the timed region then adds to)
+            distributed.reduce_device_accumulators(pt, device)
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def after():
+        reduce_s = 0.0
+        if dist is not None:
+            reduce_s = distributed.reduce_device_accumulators(pt, device)
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        return reduce_s
+
+    elapsed, st, reduce_s = timed_render(pt, args.steps, args.warmup, spp_step, first, before, after)
     rays = int(st.extend_rays + st.connect_rays)
     samples = int(st.finished_samples)
+    mine = rays / elapsed / 1e6
+    per_rank = [mine, mine]
 
     if dist is not None:
-        t = torch.tensor([elapsed, float(rays), float(samples), reduce_s], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, float(rays), float(samples), reduce_s, mine, -mine], dtype=torch.float64, device=device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -339,53 +568,28 @@ def main():
         reduce_s = float(tmax[3])
         rays = int(tsum[1])
         samples = int(tsum[2])
+        per_rank = [-float(tmax[5]), float(tmax[4])]
 
     if rank == 0:
         # ---- roofline of the dominant kernel: replay the timed samples with visit counting
-        pt.stats_reset()
-        pt.set_counting(True)
-        pt.set_sample_range(first + args.warmup * spp_step)
-        for _ in range(args.steps):
-            pt.render_spp(spp_step)
-        pt.set_counting(False)
-        cst = pt.stats()
+        cst = replay_counts(pt, [(first + args.warmup * spp_step, args.steps * spp_step)])
         assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
-        wl = f"config{args.config} {W}x{H}" + ("" if args.geometry == "knot" else f" {args.geometry}")
-        roofline = extend_roofline(pt, st, cst, elapsed, args, wl, n_paths)
+        roofline = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
-        geometry = GEOMETRY[info.procedural_dragon] if args.config >= 3 else "the reference's own assets (suzanne / teapot)"
-        out = {
-            "metric": "Mrays/s (extend+shadow), dragon 1080p",
-            "value": rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, "
-                                   f"{info.max_bounces} bounces, {spp_step} spp per step per GPU, "
-                                   f"{'per-material' if info.shade_mode else 'uber'} shading",
-                       "geometry": geometry, "paths_in_flight": n_paths, "parallelism": f"spp split x{world}"},
-            "spp_per_s": samples / (W * H) / elapsed,
-            "rays": rays,
-            "reduce_ms": reduce_s * 1e3,
-            "kernel_ms": {"extend": st.extend_ms, "extend_finish": st.finish_ms, "shade": st.shade_ms,
-                          "sample": st.sample_ms, "connect": st.connect_ms},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(out), flush=True)
+        out = result_line(args, info, W, H, n_paths, world, elapsed, rays, samples, reduce_s, st, roofline, cpu,
+                          per_rank, f"spp split x{world}" + (", one process per GPU, RCCL all-reduce" if world > 1 else ""))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     pt.close()
+    if rank == 0:
+        # the second stand-in geometry, after this context has released its 12 GB of path state
+        if (world == 1 and args.config == 3 and args.geometry == "knot" and args.mode == "render"
+                and not args.no_secondary and args.width == 0 and args.height == 0):
+            out["secondary"] = secondary_line(args, local_rank)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

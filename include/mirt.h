@@ -323,7 +323,9 @@ int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *scene);
  * place.  device_ms (may be NULL) receives the device time of build + packing.
  * The result is what mirt_scene_update_instances gives for the host-built TLAS
  * of the same transforms.  Fails (nothing changed) when the new TLAS has more
- * nodes than the room reserved at upload: 1.5 x the uploaded TLAS + 16. */
+ * nodes than the room reserved at upload: 1.5 x the uploaded TLAS + 16, and
+ * (MIRT_ERR_INVALID_ARGUMENT, before any launch) when the uploaded TLAS does not
+ * list exactly one slot per instance: the rebuilt tree lists every instance. */
 int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
                                  uint32_t n_transforms, float *device_ms);
 
@@ -411,16 +413,20 @@ int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4,
 int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                        MirtHitId *out, MirtTraversalCounts *counts);
 
-/* mirt_trace_closest for callers that cannot allocate device memory (code
- * under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc): same arguments and results, but the device-side staging (rays,
+/* mirt_trace_closest for callers that cannot allocate device memory (tight
+ * serving loops, harnesses that forbid hipMalloc, code that runs while another
+ * stream of the process is being captured into a HIP graph — an allocation there
+ * would invalidate the capture; the call itself copies from and to pageable host
+ * memory and synchronises its stream, so it cannot be captured itself):
+ * same arguments and results, but the device-side staging (rays,
  * results, visit counters, the launch's work cursor) lives in a fixed
  * file-scope device array of the library — 6 MiB + 256 B, held by every GPU the
  * library runs on until the process ends — instead of being allocated per call.
  * At most 131072 rays per call; more is MIRT_ERR_INVALID_ARGUMENT.  Calls no
  * hipMalloc / hipFree.  Every call on a GPU shares that GPU's array: calls that
- * overlap on one GPU (two contexts, two threads) race and must be serialised by
- * the caller.  No counterpart in the reference. */
+ * overlap on one GPU would race, so within one process the library serialises
+ * them (a per-device lock held for the whole, synchronous, call); two PROCESSES
+ * each have their own copy of the array.  No counterpart in the reference. */
 int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n,
                               MirtHitId *out, MirtTraversalCounts *counts);
 

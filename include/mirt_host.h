@@ -44,7 +44,9 @@ int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t se
 int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels,
                                uint32_t seed);
 /* A texture for MirtMaterial.colour_texture / emissive_texture: width x height
- * RGBA8 texels, MIRT_FILTER_*.  Returns its 1-based id (0 in a material means
+ * RGBA8 texels, MIRT_FILTER_*.  Texels are LINEAR: the sampler reads a channel as
+ * value / 255 with no transfer curve, so an sRGB-encoded image is decoded by whoever
+ * adds it (mirth_load_gltf does).  Returns its 1-based id (0 in a material means
  * none).  The reference has the ids and no texture store (src/material.rs:15-18). */
 int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter);
 /* The same from a PNG image in memory (8 or 16 bits per channel, any colour type, not
@@ -65,7 +67,10 @@ typedef struct MirthGltfInfo {
 /* A glTF 2.0 scene (.gltf with external or base64 buffers, or .glb): every triangle primitive the
  * default scene's nodes refer to becomes a mesh (positions as in the file, no normalisation), every
  * reference to it an entity with the node's world transform and the primitive's material, PNG
- * base-colour and emissive textures go to the texture store.  Finishes the loader the reference
+ * base-colour and emissive textures go to the texture store with their colour channels decoded
+ * from sRGB (what glTF defines both as) to the nearest linear 8-bit value.  A sheared world matrix
+ * is baked into a copy of the mesh (the file's normals through the inverse transpose).  The node
+ * graph must be a tree: a node reached a second time (cycle, diamond) is skipped.  Finishes the loader the reference
  * leaves commented out (src/scenes.rs:332-399).  Returns the number of entities spawned, or -1
  * (mirth_last_error says why).  `info` may be NULL. */
 int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info);

@@ -36,6 +36,10 @@ namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 unsigned char *g_scratch_ptr[kMaxDevices] = {};
+// One user of a device's array at a time within this process: the call is synchronous from its first
+// write to the array to its last read, so holding this costs nothing and two contexts on one GPU used from
+// two threads take turns instead of exchanging rays and results.
+std::mutex g_scratch_use[kMaxDevices];
 
 // With `device` current.  Returns nullptr when the address cannot be had.
 unsigned char *static_scratch(int device) {
@@ -81,6 +85,7 @@ struct mirt_ctx {
   std::vector<MirtInstance> host_instances;
   std::vector<DInst> host_insts;
   uint32_t n_transforms = 0;
+  uint32_t n_tlas_slots = 0;  // slots the uploaded TLAS lists (n_tlas_to_instances of the last upload)
 
   // state
   bool have_state = false;
@@ -823,12 +828,17 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
     HIP_TRY(ctx, copy_sync(ctx->stream, const_cast<DNode *>(sc.nodes) + sc.tlas_base, tlas.data(), tlas.size() * sizeof(DNode),
                            hipMemcpyHostToDevice));
     // a leaf of kBigLeaf or more slots keeps its size out of line, indexed by its first slot
-    std::vector<uint32_t> big(d->n_tlas_to_instances ? d->n_tlas_to_instances : 1u, 0u);
+    // both slot tables have room for one slot per instance even when the caller's TLAS lists fewer: a tree rebuilt
+    // on the device (mirt_scene_update_transforms) lists every instance
+    const size_t slot_room = std::max<size_t>(std::max(d->n_tlas_to_instances, d->n_instances), 1u);
+    std::vector<uint32_t> big(slot_room, 0u);
     for (uint32_t i = 0; i < d->n_tlas_nodes; ++i)
       if ((tlas[i].b >> 24) == kBigLeaf) big[tlas[i].a] = tlas_sizes[i];
     if ((rc = dev_upload(ctx, own, &sc.tlas_big, big)) != MIRT_OK) return rc;
     std::vector<uint32_t> t2i(d->tlas_to_instances, d->tlas_to_instances + d->n_tlas_to_instances);
+    t2i.resize(slot_room, 0u);
     if ((rc = dev_upload(ctx, own, &sc.tlas_to_inst, t2i)) != MIRT_OK) return rc;
+    ctx->n_tlas_slots = d->n_tlas_to_instances;
   }
   {
     std::vector<DInst> insts(d->n_instances);
@@ -951,6 +961,13 @@ int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
   if (!transforms || n_transforms != ctx->n_transforms)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "update_transforms: as many transforms as the scene was uploaded with");
   const uint32_t n = ctx->n_instances;
+  // The rebuilt tree lists every instance once.  A scene whose uploaded TLAS lists another number of slots (the
+  // caller left instances out, or listed one twice) is not this call's to rebuild: it would change which instances
+  // are visible.
+  if (ctx->n_tlas_slots != n)
+    return fail(ctx, MIRT_ERR_INVALID_ARGUMENT,
+                "update_transforms: the uploaded TLAS lists " + std::to_string(ctx->n_tlas_slots) + " slots for " +
+                    std::to_string(n) + " instances; use mirt_scene_update_instances");
   // instance matrices on the host (its sin / cos), as in a full upload
   std::vector<DInst> insts = ctx->host_insts;
   std::vector<float> mats((size_t)16 * n);
@@ -1379,6 +1396,7 @@ int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n, Mirt
   uint32_t *work = reinterpret_cast<uint32_t *>(d_counts + 5);
   DRay *d_rays = reinterpret_cast<DRay *>(ws + kStaticTraceRayOff);
   MirtHitId *d_out = reinterpret_cast<MirtHitId *>(ws + kStaticTraceOutOff);
+  std::lock_guard<std::mutex> one_user(g_scratch_use[ctx->device]);  // static_ws != nullptr implies device < kMaxDevices
   // the array keeps the last call's contents: counters and cursor start at zero,
   // rays and results of this call overwrite the first n records
   HIP_TRY(ctx, hipMemsetAsync(ws, 0, kStaticTraceRayOff, ctx->stream));

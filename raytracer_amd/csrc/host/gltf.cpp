@@ -65,6 +65,11 @@ struct Json {
     return (long)j->num;
   }
   size_t size() const { return kind == Arr ? arr.size() : 0; }
+  // this value itself as a non-negative integer index, or -1 (the same test as index(key))
+  long as_index() const {
+    if (kind != Num || !(num >= 0.0) || num > 4.0e9 || num != std::floor(num)) return -1;
+    return (long)num;
+  }
 };
 
 struct JsonParser {
@@ -760,6 +765,21 @@ MirtTransform identity_transform() {
 }
 
 // ------------------------------------------------------------------ the loader
+// An sRGB-encoded 8-bit colour channel as the nearest linear 8-bit value (IEC 61966-2-1's piecewise curve).
+uint32_t srgb_to_linear_rgba8(uint32_t px) {
+  static const std::vector<unsigned char> table = [] {
+    std::vector<unsigned char> t(256);
+    for (int i = 0; i < 256; ++i) {
+      const double c = i / 255.0;
+      const double lin = c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+      t[(size_t)i] = (unsigned char)std::lround(lin * 255.0);
+    }
+    return t;
+  }();
+  return (px & 0xFF000000u) | ((uint32_t)table[(px >> 16) & 0xFF] << 16) | ((uint32_t)table[(px >> 8) & 0xFF] << 8) |
+         (uint32_t)table[px & 0xFF];
+}
+
 struct Loader {
   Scene &scene;
   Doc &d;
@@ -772,8 +792,10 @@ struct Loader {
     Mesh mesh;
     std::vector<float> uvs;
     long material = -1;
+    bool file_normals = false;         // NORMAL came from the file (else face-derived)
     uint32_t shared_id = 0xFFFFFFFFu;  // MeshServer id of the unbaked mesh, once some node used it
   };
+  std::vector<char> visited;  // per node: already instanced (glTF's node graph is a strict tree)
   std::map<std::pair<long, long>, Prim> prims;
   uint32_t n_baked = 0;
 
@@ -806,6 +828,9 @@ struct Loader {
       uint32_t w = 0, h = 0;
       std::vector<uint32_t> texels;
       if (have && decode_png(bytes, w, h, texels, err) && scene.texels.size() + texels.size() <= 0xFFFFFFFFull) {
+        // glTF defines baseColorTexture and emissiveTexture (the only two slots read here) as sRGB-encoded; the
+        // sampler takes texels as linear channel / 255, so colour channels are decoded here, alpha stays
+        for (uint32_t &px : texels) px = srgb_to_linear_rgba8(px);
         uint32_t filter = MIRT_FILTER_BILINEAR;
         const Json *smp = d.at("samplers", t->index("sampler"));
         if (smp && smp->index("magFilter") == 9728) filter = MIRT_FILTER_NEAREST;
@@ -919,6 +944,7 @@ struct Loader {
       m.normals = compute_vertex_normals_ccw(m.positions, idx.data(), idx.size());
     }
     if (have_uv) out.uvs = uv;
+    out.file_normals = have_n;
     out.material = p.has("material") ? p.index("material") : -1;
     if (out.material < -1) out.material = -1;
     out.ok = true;
@@ -933,7 +959,16 @@ struct Loader {
 
   bool node(long ni, const Mat4 &parent, int depth) {
     const Json *n = d.at("nodes", ni);
-    if (!n || depth > 256) return true;  // a bad index or a cycle: ignored
+    if (!n || depth > 256) return true;  // a bad index, or a chain deeper than any real file's: ignored
+    // glTF requires a strict tree (a node has at most one parent and is no ancestor of itself).  A node reached a
+    // second time — a cycle, or a diamond, which with a fan-out of two doubles the visits per level — is skipped,
+    // so a file is walked in time linear in its node count.
+    if (visited.empty()) {
+      const Json *all = d.root.get("nodes");
+      visited.assign(all ? all->size() : 0, 0);
+    }
+    if ((size_t)ni >= visited.size() || visited[(size_t)ni]) return true;
+    visited[(size_t)ni] = 1;
     const Mat4 world = mul(parent, node_matrix(*n));
     const long mi = n->index("mesh");
     const Json *mesh = d.at("meshes", mi);
@@ -952,8 +987,9 @@ struct Loader {
         }
         mesh_id = p.shared_id;
       } else {
-        // a sheared world matrix: a copy of the mesh with the matrix applied (normals with the same
-        // matrix, as the kernels move them, then renormalised)
+        // a sheared world matrix: a copy of the mesh with the matrix applied to the positions; normals the file
+        // gave go through the inverse transpose (the cofactor matrix, signed by the determinant) and are
+        // renormalised, face-derived ones are derived again from the moved triangles
         Mesh baked = p.mesh;
         for (Vec4 &v : baked.positions) {
           const double x = v.x, y = v.y, z = v.z;
@@ -967,7 +1003,25 @@ struct Loader {
           idx.push_back(baked.faces[4 * f + 1]);
           idx.push_back(baked.faces[4 * f + 2]);
         }
-        baked.normals = compute_vertex_normals_ccw(baked.positions, idx.data(), idx.size());
+        if (p.file_normals) {
+          double c[3][3];
+          for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) {
+              const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, q1 = (q + 1) % 3, q2 = (q + 2) % 3;
+              c[r][q] = world.at(r1, q1) * world.at(r2, q2) - world.at(r1, q2) * world.at(r2, q1);
+            }
+          const double det = world.at(0, 0) * c[0][0] + world.at(0, 1) * c[0][1] + world.at(0, 2) * c[0][2];
+          const double sign = det < 0.0 ? -1.0 : 1.0;
+          for (Vec4 &nv : baked.normals) {
+            const double x = nv.x, y = nv.y, z = nv.z;
+            double o[3];
+            for (int r = 0; r < 3; ++r) o[r] = sign * (c[r][0] * x + c[r][1] * y + c[r][2] * z);
+            const double len = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+            if (len > 0.0) nv = {(float)(o[0] / len), (float)(o[1] / len), (float)(o[2] / len), 0.0f};
+          }
+        } else {
+          baked.normals = compute_vertex_normals_ccw(baked.positions, idx.data(), idx.size());
+        }
         mesh_id = add(key + "#m" + std::to_string(mi) + "p" + std::to_string(pi) + "@n" + std::to_string(ni) + "." + std::to_string(n_baked++),
                       baked, p.uvs);
         if (mesh_id == 0xFFFFFFFFu) return false;
@@ -980,7 +1034,7 @@ struct Loader {
     }
     const Json *kids = n->get("children");
     for (size_t k = 0; kids && k < kids->size(); ++k)
-      if (kids->arr[k].kind == Json::Num && !node((long)kids->arr[k].num, world, depth + 1)) return false;
+      if (kids->arr[k].as_index() >= 0 && !node(kids->arr[k].as_index(), world, depth + 1)) return false;
     return true;
   }
 };
@@ -1037,14 +1091,14 @@ bool load_gltf(Scene &scene, const std::string &path, MirthGltfInfo &info, std::
     if (si < 0 || (size_t)si >= scenes->size()) si = 0;
     const Json *nodes = scenes->arr[(size_t)si].get("nodes");
     for (size_t i = 0; nodes && i < nodes->size(); ++i)
-      if (nodes->arr[i].kind == Json::Num) roots.push_back((long)nodes->arr[i].num);
+      if (nodes->arr[i].as_index() >= 0) roots.push_back(nodes->arr[i].as_index());
   } else if (const Json *nodes = d.root.get("nodes")) {
     std::vector<char> is_child(nodes->size(), 0);
     for (const Json &n : nodes->arr) {
       const Json *kids = n.get("children");
       for (size_t k = 0; kids && k < kids->size(); ++k)
-        if (kids->arr[k].kind == Json::Num && kids->arr[k].num >= 0 && (size_t)kids->arr[k].num < is_child.size())
-          is_child[(size_t)kids->arr[k].num] = 1;
+        if (kids->arr[k].as_index() >= 0 && (size_t)kids->arr[k].as_index() < is_child.size())
+          is_child[(size_t)kids->arr[k].as_index()] = 1;
     }
     for (size_t i = 0; i < is_child.size(); ++i)
       if (!is_child[i]) roots.push_back((long)i);

@@ -110,6 +110,14 @@ def test_two_rank_gloo_reduce_of_partial_accumulators():
         allreduce_accumulators(t4, tc)
         full4, fullc, _ = sc.render(cam, src, W, H, prm, 0, spp)
         ok = np.array_equal(t4.numpy().view(np.uint32), full4) and np.array_equal(tc.numpy().view(np.uint32), fullc)
+        # sums that overflow 32 bits only when the ranks' shares are added saturate, as they do on one GPU
+        # and in mirt_group_reduce; the ones that fit are exact; counts wrap
+        part = np.array([0xC0000000, 0x7FFFFFFF, 5, 0xFFFFFFFF, 0x80000000 if rank == 0 else 0x7FFFFFFF, 0, 1, 2], np.uint32)
+        u4 = torch.from_numpy(part.view(np.int32).copy()); uc = torch.from_numpy(np.array([0xFFFFFFFF, 7], np.uint32).view(np.int32).copy())
+        allreduce_accumulators(u4, uc)
+        want = np.array([0xFFFFFFFF, 0xFFFFFFFE, 10, 0xFFFFFFFF, 0xFFFFFFFF, 0, 2, 4], np.uint32)
+        ok = ok and np.array_equal(u4.numpy().view(np.uint32), want)
+        ok = ok and np.array_equal(uc.numpy().view(np.uint32), np.array([0xFFFFFFFE, 14], np.uint32))
         print("RANK", rank, "OK" if ok else "MISMATCH", flush=True)
         dist.destroy_process_group()
         sys.exit(0 if ok else 1)
@@ -124,3 +132,31 @@ def test_two_rank_gloo_reduce_of_partial_accumulators():
                              capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 2
+
+
+def _bench(*argv, env=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=120, env=env)
+
+
+def test_bench_starts_one_process_per_gpu_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two fresh rank processes (before anything
+    touches torch or HIP) with the rank environment torch.distributed.run would give them."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = _bench("--gpus", "2", "--dry-launch", env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    assert sorted(l["RANK"] for l in lines) == ["0", "1"]
+    assert all(l["WORLD_SIZE"] == "2" and l["LOCAL_RANK"] == l["RANK"] and l["MASTER_ADDR"] == "127.0.0.1" for l in lines)
+    assert len({l["MASTER_PORT"] for l in lines}) == 1 and len({l["pid"] for l in lines}) == 2
+    # under a launcher (WORLD_SIZE set) it is a rank itself and starts nothing
+    out = _bench("--gpus", "2", "--dry-launch", env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"))
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1 and lines[0]["RANK"] == "1"
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = _bench("--gpus", "2", "--dry-launch", env=dict(env, MIRT_BENCH_DRY_FAIL_RANK="1"))
+    assert out.returncode != 0 and "ranks failed" in out.stderr

@@ -313,6 +313,16 @@ def build_document(tmp_path, mode):
     return path, world, tex_img
 
 
+def srgb8_to_linear8(img):
+    """IEC 61966-2-1 decoding of the three colour channels of an RGBA8 image to the nearest linear 8-bit value."""
+    c = np.arange(256) / 255.0
+    table = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    table = np.floor(table * 255.0 + 0.5).astype(np.uint32)
+    out = np.asarray(img).astype(np.uint32).copy()
+    out[..., :3] = table[out[..., :3]]
+    return out
+
+
 def geometry_of(arrays, g):
     go = arrays["geometry_offsets"]
     v0 = int(go["vertex"][g])
@@ -371,7 +381,11 @@ def test_gltf_scene_graph_meshes_materials_textures(tmp_path, mode):
     # textures: the same image twice, the first with the NEAREST sampler
     tex = arrays["textures"]
     assert [int(t["filter"]) for t in tex] == [ffi.FILTER_NEAREST, ffi.FILTER_BILINEAR]
-    want = rgba(tex_img[..., 0], tex_img[..., 1], tex_img[..., 2], tex_img[..., 3]).reshape(-1)
+    # base-colour and emissive images are sRGB-encoded in glTF: the store holds the decoded (linear) colour
+    # channels, alpha as it is
+    lin = srgb8_to_linear8(tex_img)
+    assert lin[..., :3].max() < tex_img[..., :3].max() and np.array_equal(lin[..., 3], tex_img[..., 3])
+    want = rgba(lin[..., 0], lin[..., 1], lin[..., 2], lin[..., 3]).reshape(-1)
     assert np.array_equal(arrays["texels"], np.concatenate([want, want]))
     assert tuple(tex[0][["width", "height"]]) == (4, 3)
     # light sources: the instance with the emissive material
@@ -431,6 +445,64 @@ def test_gltf_without_scenes_uses_the_root_nodes_and_errors_are_reported(tmp_pat
     with pytest.raises(host.HostError, match="cannot open"):
         s.load_gltf(str(tmp_path / "missing.gltf"))
     s.close()
+
+
+def test_gltf_node_graph_that_is_no_tree_is_walked_once(tmp_path):
+    """glTF demands a strict tree.  A node that lists itself, a cycle through several nodes and a diamond forty
+    levels deep (2^40 paths) each load at once, every node instanced the first time it is reached; a child index
+    that is no finite integer is ignored."""
+    import time
+    g = Gltf()
+    g.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": g.accessor(QUAD_POS, "VEC3", 5126)},
+                                        "indices": g.accessor(QUAD_IDX, "SCALAR", 5123)}]}]
+
+    def load(nodes, roots, name, patch=None):
+        g.doc["nodes"] = nodes
+        g.doc["scenes"] = [{"nodes": roots}]
+        path = str(tmp_path / name)
+        g.finish(path, "embedded")
+        if patch:
+            text = open(path).read()
+            assert patch[0] in text
+            open(path, "w").write(text.replace(*patch))
+        s = host.Scene()
+        t0 = time.perf_counter()
+        info = s.load_gltf(path)
+        assert time.perf_counter() - t0 < 5.0
+        s.close()
+        return info["n_instances"]
+
+    assert load([{"mesh": 0, "children": [0, 0]}], [0], "self.gltf") == 1
+    assert load([{"mesh": 0, "children": [1]}, {"mesh": 0, "children": [2, 0]}, {"mesh": 0, "children": [0, 1]}], [0], "cycle.gltf") == 3
+    diamond = [{"mesh": 0, "children": [i + 1, i + 1]} for i in range(40)] + [{"mesh": 0}]
+    assert load(diamond, [0], "diamond.gltf") == 41
+    assert load([{"mesh": 0, "children": [1, 987654321]}, {"mesh": 0}], [0], "huge.gltf", ("987654321", "1e999")) == 2
+
+
+def test_gltf_baked_mesh_keeps_the_files_normals(tmp_path):
+    """A sheared node bakes its matrix into a copy of the mesh: positions by the matrix, the file's normals by its
+    inverse transpose (renormalised) — not re-derived from the faces."""
+    g = Gltf()
+    tilted = np.array([[0.6, 0.0, 0.8]] * 4, "<f4")  # authored normals that no face of the flat quad would give
+    g.doc["meshes"] = [{"primitives": [{"attributes": {"POSITION": g.accessor(QUAD_POS, "VEC3", 5126),
+                                                       "NORMAL": g.accessor(tilted, "VEC3", 5126)},
+                                        "indices": g.accessor(QUAD_IDX, "SCALAR", 5123)}]}]
+    m = np.array([[1, 0.5, 0.25, 2], [0, 1.5, 0, 0], [0.3, 0, 1, -3], [0, 0, 0, 1]], float)
+    mirror = m @ np.diag([-1.0, 1, 1, 1])
+    g.doc["nodes"] = [{"mesh": 0, "matrix": m.T.reshape(-1).tolist()}, {"mesh": 0, "matrix": mirror.T.reshape(-1).tolist()}]
+    g.doc["scenes"] = [{"nodes": [0, 1]}]
+    path = str(tmp_path / "sheared.gltf")
+    g.finish(path, "embedded")
+    s = host.Scene()
+    assert s.load_gltf(path)["n_baked"] == 2
+    arrays = s.bind()
+    s.close()
+    for k, mat in enumerate((m, mirror)):
+        v, _ = geometry_of(arrays, int(arrays["instances"][k]["geometry"]))
+        want = np.linalg.inv(mat[:3, :3]).T @ np.array([0.6, 0.0, 0.8])
+        want /= np.linalg.norm(want)
+        assert np.allclose(v["normal"][:, :3], want, atol=1e-6), k
+        assert np.allclose(v["position"][:, :3], QUAD_POS @ mat[:3, :3].T + mat[:3, 3], atol=1e-6)
 
 
 @pytest.mark.gpu

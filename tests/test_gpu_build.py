@@ -285,3 +285,40 @@ def test_transforms_only_update_refuses_a_tree_that_outgrew_its_room(pt):
     with pytest.raises(pathtracer.MirtError, match="outgrew"):
         pt.update_transforms(apart)
     assert hits_equal(pt.trace_closest(rays), before)   # the scene was left as it was
+
+
+def test_transforms_only_update_refuses_a_tlas_that_leaves_instances_out(pt):
+    """A caller-built TLAS may list fewer slots than there are instances (validation only asks that every slot
+    names an instance).  The transforms-only update rebuilds a tree over every instance, so it refuses such a
+    scene before any launch and leaves it as it was; the slot tables have room for every instance all the same."""
+    from conftest import hits_equal, random_rays
+    from oracle import pyoracle as po
+    s = host.Scene()
+    cube = s.load_cube()
+    mat = s.add_material(host.make_material())
+    for i in range(6):
+        s.spawn(host.make_transform(translation=(3.0 * i, 0.0, 0.0)), mat, cube)
+    arrays = s.bind()
+    s.close()
+    roots = arrays["blas_nodes"][arrays["geometry_offsets"]["blas_node"]]
+    aabbs = np.concatenate([roots["lb"][:, :3], roots["ub"][:, :3]], axis=1)
+    partial = {k: v.copy() for k, v in arrays.items()}
+    partial["tlas_nodes"], partial["tlas_to_instances"], _ = pt.build_tlas(aabbs, arrays["transforms"], arrays["instances"][:4])
+    assert len(partial["tlas_to_instances"]) == 4 and len(partial["instances"]) == 6
+    rays = random_rays(4000, 11, centre=(7.5, 0.0, 0.0), spread=9.0)
+    pt.upload_scene(partial)
+    before = pt.trace_closest(rays)
+    assert hits_equal(before, po.Scene(partial).trace_closest(rays))
+    assert before["instance_id"][before["instance_id"] != ffi.NO_HIT].max() < 4   # the two instances left out are invisible
+    moved = arrays["transforms"].copy()
+    moved["translation"][:, 1] += 1.0
+    with pytest.raises(pathtracer.MirtError, match="lists 4 slots for 6 instances"):
+        pt.update_transforms(moved)
+    assert hits_equal(pt.trace_closest(rays), before)
+    # the full TLAS of the same instances takes the update
+    pt.upload_scene(arrays)
+    pt.update_transforms(moved)
+    full = {k: v.copy() for k, v in arrays.items()}
+    full["transforms"] = moved
+    full["tlas_nodes"], full["tlas_to_instances"], _ = pt.build_tlas(aabbs, moved, arrays["instances"])
+    assert hits_equal(pt.trace_closest(rays), po.Scene(full).trace_closest(rays))
