@@ -64,6 +64,10 @@ def parse():
                          "reference's operating point (512x512, one path slot per pixel, src/pathtracer.rs:34-38)")
     ap.add_argument("--frames-per-step", type=int, default=64, help="step mode: frames per bench step")
     ap.add_argument("--step-paths-per-pixel", type=int, default=1, help="step mode: path slots per pixel")
+    ap.add_argument("--rng", choices=["per-sample", "per-slot"], default="per-sample",
+                    help="step mode: per-sample keyed streams (the default everywhere) or the reference's persistent "
+                         "stream per path slot (src/pathtracer_state.rs:98-110), which the Rust shim selects; the sample "
+                         "stage then pairs slots with sample numbers in ascending slot order")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,8 +280,14 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
     import torch
     ppp = args.step_paths_per_pixel
     n_paths = W * H * ppp  # Pathtracer.threads = dims.0 * dims.1 in the reference (ppp = 1)
+    if args.rng == "per-slot":
+        from raytracer_amd import ffi
+        params.rng_mode = ffi.RNG_PER_SLOT
     pt.create_state(W, H, n_paths, src, params)
     pt.set_camera(cam)
+    if args.rng == "per-slot":
+        # PathtracerState::new: every word of every slot's state uniform in [1000, 2^32)
+        pt.set_rng(np.random.default_rng(info.seed).integers(1000, 2 ** 32, size=(n_paths, 4), dtype=np.uint64).astype("<u4"))
     F = args.frames_per_step
     for _ in range(args.warmup):
         for _ in range(F):
@@ -316,7 +326,7 @@ def step_mode(args, pt, info, W, H, src, cam, params, world):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, {info.max_bounces} bounces, "
-                               f"mirt_step(1) per frame, {F} frames per step, "
+                               f"mirt_step(1) per frame, {F} frames per step, {args.rng} random streams, "
                                f"{'per-material' if info.shade_mode else 'uber'} shading",
                    "geometry": geometry, "paths_in_flight": n_paths, "parallelism": "one GPU"},
         "frames_per_s": frames / elapsed, "wall_ms_per_frame": wall_ms_per_frame,

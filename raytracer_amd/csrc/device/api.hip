@@ -1078,6 +1078,9 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if (params->rng_mode == MIRT_RNG_PER_SLOT) {
     if ((rc = dev_alloc(ctx, own, &st.slot_stamp, threads)) != MIRT_OK) return rc;
     HIP_TRY(ctx, hipMemsetAsync(st.slot_stamp, 0, (size_t)4 * threads, ctx->stream));
+    const size_t ws_words = 8u + ((size_t)threads + kStreamBlock - 1u) / kStreamBlock;
+    if ((rc = dev_alloc(ctx, own, &st.ordered_ws, ws_words)) != MIRT_OK) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(st.ordered_ws, 0, 4 * ws_words, ctx->stream));
   }
   ctx->st = st;
   ctx->params = *params;

@@ -57,6 +57,7 @@ struct DState {
   uint32_t n_active;            // entries of `active`; n_sources when it is null
   // per-slot random streams (MIRT_RNG_PER_SLOT): the frame a slot was last seen on the terminate queue
   uint32_t *slot_stamp;         // [slots], null in per-sample mode
+  uint32_t *ordered_ws;         // [8 + tiles of kStreamBlock slots]: ticket, frame bases, per-tile counts / prefixes
 };
 
 struct DFrameParams {

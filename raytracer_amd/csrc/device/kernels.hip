@@ -202,10 +202,21 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
 // slots that ended in a frame with the next sample numbers is a run it can make.
 // This picks ONE of them so that runs can be compared: the slots of the
 // terminate queue take the next sample numbers in ascending slot order.
-// k_mark_terminated (any grid) accumulates the finished samples and stamps the
-// slots; k_sample_ordered (ONE block) walks all slots in order, ranks the
-// stamped ones with a block scan and spawns.  Cost grows with the number of
-// slots on one CU: a mode for reference-faithful comparison runs, not for speed.
+// Three launches, every one over the whole grid:
+//   k_mark_terminated  accumulates the finished samples and stamps their slots
+//   k_ordered_count    counts the stamped slots of every tile of kStreamBlock
+//                      consecutive slots; the block that finishes last turns the
+//                      counts into exclusive prefixes and settles the frame's
+//                      totals (sample counter, extension queue length)
+//   k_ordered_spawn    ranks every stamped slot (tile prefix + rank inside the
+//                      tile) and spawns sample `base + rank` into it; sample
+//                      numbers rise with the slot, so the slots that still get
+//                      one are a prefix of the stamped ones and a slot's rank is
+//                      also its place behind the bounce rays already on the
+//                      extension queue
+static_assert(kStreamBlock % 64u == 0u && kStreamBlock >= 64u && kStreamBlock <= 1024u, "whole waves, at most sixteen");
+constexpr uint32_t kStreamWaves = kStreamBlock / 64u;
+
 __global__ __launch_bounds__(kStreamBlock) void k_mark_terminated(DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *term = st.qdata[Q_TERM0 + par];
@@ -225,57 +236,83 @@ __global__ __launch_bounds__(kStreamBlock) void k_mark_terminated(DState st, DFr
   if (lane_id() == 0u && finished) atomicAdd(&st.stats[S_FINISHED], finished);
 }
 
-__global__ __launch_bounds__(kStreamBlock) void k_sample_ordered(DState st, DFrameParams fp) {
-  __shared__ uint32_t wave_count[16];
-  __shared__ uint32_t wave_spawn[16];
-  const uint32_t par = fp.frame & 1u;
-  uint32_t *ext = st.qdata[Q_EXT0 + par];
-  const CamBasis cb = cam_basis(fp.cam);
+// Words of DState::ordered_ws: the ticket the blocks of k_ordered_count draw, the frame's
+// bases for k_ordered_spawn, then one word per tile.
+enum OrderedWs { OW_TICKET = 0, OW_EXT_BASE, OW_SAMPLE_BASE_LO, OW_SAMPLE_BASE_HI, OW_TILES = 8 };
+
+__device__ __forceinline__ uint32_t agent_load(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_store(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kStreamBlock) void k_ordered_count(DState st, DFrameParams fp) {
+  __shared__ uint32_t wave_sum[kStreamWaves];
+  __shared__ uint32_t is_last;
   const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-  unsigned long long next_sample = *st.sample_index;  // only this block touches it in this frame
-  uint32_t ext_count = st.qcount[Q_EXT0 + par];      // bounce rays pushed by the last frame's shade kernels
-  unsigned long long spawned = 0;
-  for (uint32_t base = 0; base < st.slots; base += kStreamBlock) {  // uniform
-    const uint32_t slot = base + tid;
+  const uint32_t n_tiles = (st.slots + kStreamBlock - 1u) / kStreamBlock;
+  uint32_t *ws = st.ordered_ws;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // uniform per block
+    const uint32_t slot = tile * kStreamBlock + tid;
     const bool ended = slot < st.slots && st.slot_stamp[slot] == fp.stamp;
     const unsigned long long m = __ballot(ended);
-    if (lane == 0u) wave_count[wid] = (uint32_t)__popcll(m);
+    if (lane == 0u) wave_sum[wid] = (uint32_t)__popcll(m);
     __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < 16u; ++w) {
-      const uint32_t c = wave_count[w];
-      if (w < wid) before += c;
-      total += c;
+    if (tid == 0u) {
+      uint32_t total = 0;
+      for (uint32_t w = 0; w < kStreamWaves; ++w) total += wave_sum[w];
+      agent_store(&ws[OW_TILES + tile], total);
     }
-    const unsigned long long si = next_sample + before + rank_in_mask(m);
-    const bool spawn = ended && si < fp.sample_limit;
-    if (spawn) {
-      spawn_sample(st, fp, cb, slot, si);
-      spawned++;
-    } else if (ended) {
-      reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
-    }
-    // the spawned slots join the extension queue, still in slot order
-    const unsigned long long ms = __ballot(spawn);
-    if (lane == 0u) wave_spawn[wid] = (uint32_t)__popcll(ms);
-    __syncthreads();
-    uint32_t sbefore = 0, stotal = 0;
-    for (uint32_t w = 0; w < 16u; ++w) {
-      const uint32_t c = wave_spawn[w];
-      if (w < wid) sbefore += c;
-      stotal += c;
-    }
-    if (spawn) ext[ext_count + sbefore + rank_in_mask(ms)] = slot;
-    ext_count += stotal;
-    next_sample += total;
     __syncthreads();
   }
-  for (int off = 32; off > 0; off >>= 1) spawned += __shfl_down(spawned, off);
-  if (lane == 0u && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+  // the block that draws the last ticket sees every tile's count
+  __threadfence();
+  if (tid == 0u) is_last = atomicAdd(&ws[OW_TICKET], 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (is_last == 0u) return;
+  __threadfence();
+  // exclusive prefix over the tiles: a run of consecutive tiles per thread, the runs' sums scanned over the block
+  const uint32_t per = (n_tiles + kStreamBlock - 1u) / kStreamBlock;
+  const uint32_t t0 = tid * per < n_tiles ? tid * per : n_tiles;
+  const uint32_t t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+  uint32_t mine = 0;
+  for (uint32_t t = t0; t < t1; ++t) mine += agent_load(&ws[OW_TILES + t]);
+  uint32_t x = mine;  // inclusive scan within the wave
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  if (lane == 63u) wave_sum[wid] = x;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (uint32_t w = 0; w < kStreamWaves; ++w) {
+    const uint32_t c = wave_sum[w];
+    if (w < wid) before += c;
+    total += c;
+  }
+  uint32_t run = before + x - mine;
+  for (uint32_t t = t0; t < t1; ++t) {
+    const uint32_t c = agent_load(&ws[OW_TILES + t]);
+    agent_store(&ws[OW_TILES + t], run);
+    run += c;
+  }
   if (tid == 0u) {
-    *st.sample_index = next_sample;
-    st.qcount[Q_EXT0 + par] = ext_count;
-    // clear the counters of the queues that are idle during this kernel
+    const uint32_t par = fp.frame & 1u;
+    // every stamped slot draws a sample number (shaders/sample.slang:64-68), whether or not the call
+    // still has a sample for it
+    const unsigned long long base = *st.sample_index;
+    const unsigned long long room = fp.sample_limit > base ? fp.sample_limit - base : 0ull;
+    const uint32_t spawned = (unsigned long long)total < room ? total : (uint32_t)room;
+    const uint32_t ext_base = st.qcount[Q_EXT0 + par];  // bounce rays pushed by the last frame's shade kernels
+    ws[OW_EXT_BASE] = ext_base;
+    ws[OW_SAMPLE_BASE_LO] = (uint32_t)base;
+    ws[OW_SAMPLE_BASE_HI] = (uint32_t)(base >> 32);
+    *st.sample_index = base + total;
+    st.qcount[Q_EXT0 + par] = ext_base + spawned;
+    if (spawned) atomicAdd(&st.stats[S_SPAWNED], (unsigned long long)spawned);
+    ws[OW_TICKET] = 0u;
+    // clear the counters of the queues that are idle during the sample stage
     st.qcount[Q_TERM0 + (par ^ 1u)] = 0u;
     st.qcount[Q_EXT0 + (par ^ 1u)] = 0u;
     st.qcount[Q_CONNECT] = 0u;
@@ -285,6 +322,37 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample_ordered(DState st, DFra
     st.qcount[Q_EMISSIVE] = 0u;
     st.qcount[W_EXTEND] = 0u;
     st.qcount[W_CONNECT] = 0u;
+  }
+}
+
+__global__ __launch_bounds__(kStreamBlock) void k_ordered_spawn(DState st, DFrameParams fp) {
+  __shared__ uint32_t wave_count[kStreamWaves];
+  const uint32_t par = fp.frame & 1u;
+  uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const CamBasis cb = cam_basis(fp.cam);
+  const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+  const uint32_t n_tiles = (st.slots + kStreamBlock - 1u) / kStreamBlock;
+  const uint32_t *ws = st.ordered_ws;
+  const uint32_t ext_base = ws[OW_EXT_BASE];
+  const unsigned long long sample_base = (unsigned long long)ws[OW_SAMPLE_BASE_LO] | ((unsigned long long)ws[OW_SAMPLE_BASE_HI] << 32);
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // uniform per block
+    const uint32_t slot = tile * kStreamBlock + tid;
+    const bool ended = slot < st.slots && st.slot_stamp[slot] == fp.stamp;
+    const unsigned long long m = __ballot(ended);
+    if (lane == 0u) wave_count[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = ws[OW_TILES + tile];
+    for (uint32_t w = 0; w < kStreamWaves; ++w)
+      if (w < wid) before += wave_count[w];
+    const uint32_t rank = before + rank_in_mask(m);
+    const unsigned long long si = sample_base + rank;
+    if (ended && si < fp.sample_limit) {
+      spawn_sample(st, fp, cb, slot, si);
+      ext[ext_base + rank] = slot;  // the spawned slots join the extension queue in slot order
+    } else if (ended) {
+      reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+    }
+    __syncthreads();
   }
 }
 
@@ -887,7 +955,8 @@ void launch_sample(const LaunchCfg &cfg, const DScene &, const DState &st, const
 
 void launch_sample_ordered(const LaunchCfg &cfg, const DScene &, const DState &st, const DFrameParams &fp) {
   hipLaunchKernelGGL(k_mark_terminated, stream_grid(cfg, k_mark_terminated), dim3(kStreamBlock), 0, cfg.stream, st, fp);
-  hipLaunchKernelGGL(k_sample_ordered, dim3(1), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+  hipLaunchKernelGGL(k_ordered_count, stream_grid(cfg, k_ordered_count), dim3(kStreamBlock), 0, cfg.stream, st, fp);
+  hipLaunchKernelGGL(k_ordered_spawn, stream_grid(cfg, k_ordered_spawn), dim3(kStreamBlock), 0, cfg.stream, st, fp);
 }
 
 void launch_adapt_update(const LaunchCfg &cfg, const DState &st, double threshold_squared, uint32_t min_samples) {

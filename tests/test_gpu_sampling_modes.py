@@ -63,6 +63,40 @@ def test_per_slot_streams_match_the_oracle_simulation(pt, config_scenes, cfg, W,
         assert not np.array_equal(pt.read_accum()[0], w4)
 
 
+@pytest.mark.parametrize("W,H,slots,frames,spp", [(160, 120, 70001, 7, 0), (256, 256, 1024 * 1025 + 3, 3, 0),
+                                                  (96, 96, 5000, 0, 3)])
+def test_per_slot_sample_stage_over_many_tiles(pt, config_scenes, W, H, slots, frames, spp):
+    """The ordered sample stage on slot counts that span many tiles of 1024 slots (one block per tile, the
+    tile prefixes from the block that finishes last — with more than 1024 tiles a run of tiles per thread), and
+    with a sample budget that runs out in the middle of a tile: sums, counts and statistics of the oracle's
+    sequential simulation, where the slots of the terminate queue take sample numbers in ascending slot order."""
+    arrays, info = config_scenes(1)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    rng = host_seeds(slots, 5)
+    kw = dict(max_bounces=info.max_bounces, seed=info.seed, rng_mode=ffi.RNG_PER_SLOT)
+    prm, oprm = pathtracer.default_params(**kw), po.default_params(**kw)
+    pt.create_state(W, H, slots, src, prm)
+    pt.set_camera(cam)
+    pt.set_rng(rng)
+    pt.stats_reset()
+    if spp == 0:
+        pt.step(frames)
+        w4, wcnt, wst = sc.wavefront_per_slot(cam, src, W, H, oprm, rng, 2 ** 62, frames, slots)
+    else:
+        # a render call hands out exactly spp samples per source however many slots ask in its last frames
+        # (27 648 samples over 5 000 slots: the budget runs out in the middle of a tile)
+        pt.render_spp(spp)
+        w4, wcnt, wst = sc.wavefront_per_slot(cam, src, W, H, oprm, rng, spp * len(src), 2 ** 62, slots)
+    s4, cnt = pt.read_accum()
+    assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4)
+    st = pt.stats()
+    assert (st.extend_rays, st.shade_events, st.finished_samples) == (wst.extend_rays, wst.shade_events, wst.finished_samples)
+    assert wst.finished_samples > 0
+
+
 def test_adaptive_sampling_flags_and_skips_like_the_oracle(pt, config_scenes):
     # configuration 1 (suzanne under a light, 256 x 256) with a fixed threshold: rounds of 8
     # samples per still-active source, a convergence pass after each
