@@ -281,10 +281,15 @@ typedef struct MirtStats {
    * render fewer samples per accumulator or lower fixed_point_scale. */
   uint64_t overflowed_sums;
   /* diagnostic builds only (-DMIRT_PHASE_TIMING), summed over the waves of the
-   * extend kernel: service points, lane node steps, lane triangle steps,
-   * whole-wave leaves, shader-clock cycles, loop iterations, walking lanes summed
-   * over iterations, unused. */
-  uint64_t engine_phase[8];
+   * extend kernel (times in ticks of the 100 MHz constant clock): [0] service
+   * points, [1] lane node steps, [2] service-point time with 5..16 lanes walking,
+   * [3] whole-wave leaves, [4] wave time, [5] step iterations, [6] walking lanes
+   * summed over iterations, [7] time in whole-wave scans, [8] the slowest wave's
+   * time (a maximum, not a sum), [9] step iterations with at most 4 lanes
+   * walking, [10] step-loop time with at most 4, [11] service-point time with at
+   * most 4, [12] step iterations with 5..16, [13] step-loop time with 5..16,
+   * [14] service-point time, [15] step-loop time. */
+  uint64_t engine_phase[16];
 } MirtStats;
 
 typedef struct mirt_ctx mirt_ctx;

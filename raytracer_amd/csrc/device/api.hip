@@ -1483,7 +1483,7 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
     out->connect_tri_wave_lds = s[S_CON_TRI_LDS];
     out->connect_tri_wave_mem = s[S_CON_TRI_MEM];
     out->overflowed_sums = s[S_OVERFLOW];
-    for (int k = 0; k < 8; ++k) out->engine_phase[k] = s[S_PHASE0 + k];
+    for (int k = 0; k < 16; ++k) out->engine_phase[k] = s[S_PHASE0 + k];
   }
   out->frames = ctx->frames_total;
   out->extend_launches = ctx->kernel_launches[K_EXTEND];   out->extend_ms = ctx->kernel_ms[K_EXTEND];

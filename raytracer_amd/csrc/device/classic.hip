@@ -119,8 +119,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
   // Light sampling happens when the slot is fetched.  A slot whose sample lies
   // behind its surface traces nothing: it gets a ray that cannot hit anything
   // (tmax < 0 rejects the TLAS root) and is not counted.
-  auto fetch = [&](uint32_t idx, RayIn &r) {
-    const uint32_t slot = cq[idx];
+  auto fetch = [&](uint32_t slot, RayIn &r) {
     const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
     const float4 ha = h4[0], hb = h4[1];
     const uint32_t inst_ff = __float_as_uint(ha.w);
@@ -183,7 +182,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
   auto finish = [&](bool fin, uint32_t slot, bool occluded, float, const BestHit &) {
     if (fin) reinterpret_cast<float *>(st.shadow + slot)[7] = occluded ? 1.0f : 0.0f;
   };
-  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, nullptr}, lc, fetch, finish);
+  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, cq, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
   if (COUNT) flush_wave_scan_counts(st.stats, S_CON_TRI_LDS, lc);
   for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);

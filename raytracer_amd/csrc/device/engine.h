@@ -146,14 +146,19 @@ struct RayIn {
 #define MIRT_WORK_CHUNK 128u
 #endif
 constexpr uint32_t kChunk = MIRT_WORK_CHUNK;
+#ifndef MIRT_PREFETCH_HK
+#define MIRT_PREFETCH_HK 1
+#endif
+constexpr bool kPrefetchHk = MIRT_PREFETCH_HK != 0;
 struct WorkSource {
   uint32_t *counter;  // zeroed before the launch
   uint32_t count;     // number of queue entries
+  const uint32_t *entries;  // the queue: fetch() is handed entries[i] for entry i, or i itself when this is null
   unsigned long long *phase;  // diagnostic builds: eight cycle / iteration sums, else unused
 };
 
 #ifdef MIRT_PHASE_TIMING
-#define MIRT_PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_start = ph_t0, ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MIRT_PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(), ph_start = ph_t0, ph_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define MIRT_PH_MARK(k)                                        \
   do {                                                         \
     const unsigned long long ph_now = __builtin_amdgcn_s_memtime(); \
@@ -163,11 +168,15 @@ struct WorkSource {
 #define MIRT_PH_RESET (ph_t0 = __builtin_amdgcn_s_memtime())
 #define MIRT_PH_COUNT(k) (ph_acc[k] += 1ull)
 #define MIRT_PH_ADD(k, n) (ph_acc[k] += (unsigned long long)(n))
+#define MIRT_PH_NOW() __builtin_amdgcn_s_memtime()
 #define MIRT_PH_FLUSH(ptr)                                                        \
   do {                                                                            \
     ph_acc[4] = __builtin_amdgcn_s_memtime() - ph_start;                          \
-    if ((ptr) != nullptr && trv_lane() == 0u)                                     \
-      for (int ph_k = 0; ph_k < 8; ++ph_k) atomicAdd(&(ptr)[ph_k], ph_acc[ph_k]); \
+    if ((ptr) != nullptr && trv_lane() == 0u) {                                   \
+      for (int ph_k = 0; ph_k < 16; ++ph_k)                                       \
+        if (ph_k != 8) atomicAdd(&(ptr)[ph_k], ph_acc[ph_k]);                     \
+      atomicMax(&(ptr)[8], ph_acc[4]); /* the slowest wave */                     \
+    }                                                                             \
   } while (0)
 #else
 #define MIRT_PH_DECL
@@ -175,6 +184,7 @@ struct WorkSource {
 #define MIRT_PH_RESET
 #define MIRT_PH_COUNT(k)
 #define MIRT_PH_ADD(k, n)
+#define MIRT_PH_NOW() 0ull
 #define MIRT_PH_FLUSH(ptr)
 #endif
 
@@ -231,8 +241,7 @@ __device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
   return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
 }
 
-// The engine.  `fetch(index, ray)` loads entry `index` of the client's queue
-// (called by single lanes); `finish(fin, payload, found, t, best)` is called by
+// The engine.  `fetch(entry, ray)` loads the ray of a queue entry (WorkSource::entries; called by single lanes); `finish(fin, payload, found, t, best)` is called by
 // ALL lanes at every refill point, with fin = true on the lanes whose ray is
 // done, so it may use wave-aggregated pushes.
 //
@@ -270,7 +279,10 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   const BufferRsrc geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(sc.geo), 0, (int)sc.geo_bytes, 0x00020000);
   const uint32_t tlas_nbase = sc.tlas_base * 32u;
 
-  // wave-uniform work cursor
+  // wave-uniform work cursor.  A launch with fewer than kChunk entries per wave of the grid hands out chunks
+  // of 64: with 128 only half of the waves would find work, each with two rays for every lane, and a launch
+  // that small lasts as long as its slowest wave (the per-frame call at 512 x 512: 1.27 -> 1.10 ms).
+  const uint32_t chunk = ws.count >= kChunk * (kEngineBlock / 64u) * gridDim.x ? kChunk : (kChunk < 64u ? kChunk : 64u);
   uint32_t chunk_next = 0, chunk_end = 0;
   bool exhausted = false;
 
@@ -310,7 +322,22 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
     if ((n_held != 0 && kServiceFrac * n_held >= n_walking) || n_held == n_walking ||
         (!exhausted && n_walking < kRefillBelow)) {
       MIRT_PH_COUNT(0);
+#ifdef MIRT_PHASE_TIMING
+      const unsigned long long ph_sp0 = MIRT_PH_NOW();
+#endif
       // ================================================== service point
+      // What the housekeeping below asks memory for first — the instance behind the next TLAS slot of a lane
+      // that comes back from a BLAS or stands on a TLAS leaf, and that leaf's size — is requested now, so that it
+      // arrives under the leaf tests instead of after them (one round trip less per service point: 1.7 %).
+      uint32_t pf_id = 0u, pf_big = 0u;
+      if (kPrefetchHk) {
+        const bool held = (fl & (F_WALK | F_HOLD)) == (F_WALK | F_HOLD);
+        const bool in_blas = (fl & F_BLAS) != 0u;
+        if (held && (in_blas ? ((fl & F_WRAP) != 0u && slot_next < slot_stop) : leaf_count != 0u)) {
+          pf_id = sc.tlas_to_inst[in_blas ? slot_next : leaf_start];
+          if (!in_blas) pf_big = leaf_count == kBigLeaf ? sc.tlas_big[leaf_start] : leaf_count;
+        }
+      }
       // ------------------------------------- leaves for the whole wave
       {
         unsigned long long bigmask =
@@ -532,12 +559,12 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
               if ((fl & F_WRAP) != 0u) fl |= F_TDONE;
               if (leaf_count != 0u) {
                 slot_i = leaf_start;
-                slot_end = leaf_start + (leaf_count == kBigLeaf ? sc.tlas_big[leaf_start] : leaf_count);
+                slot_end = leaf_start + (kPrefetchHk ? pf_big : (leaf_count == kBigLeaf ? sc.tlas_big[leaf_start] : leaf_count));
                 leaf_count = 0u;
               }
             }
             if (slot_i < slot_end) {
-              const uint32_t id = sc.tlas_to_inst[slot_i];
+              const uint32_t id = kPrefetchHk ? pf_id : sc.tlas_to_inst[slot_i];
               const DInst *inst = &sc.inst[id];
               if (COUNT) lc.instance_visits++;
               const float4 m0 = reinterpret_cast<const float4 *>(inst->mi)[0];
@@ -587,16 +614,16 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
           const unsigned long long need = __ballot((fl & F_HAS) == 0u);
           if (chunk_next >= chunk_end) {
             uint32_t cbase = 0;
-            if (lane == 0u) cbase = atomicAdd(ws.counter, kChunk);
+            if (lane == 0u) cbase = atomicAdd(ws.counter, chunk);
             cbase = (uint32_t)__shfl((int)cbase, 0);
             chunk_next = cbase < ws.count ? cbase : ws.count;
-            chunk_end = cbase + kChunk < ws.count ? cbase + kChunk : ws.count;
+            chunk_end = cbase + chunk < ws.count ? cbase + chunk : ws.count;
             if (chunk_next >= chunk_end) exhausted = true;
           }
           const uint32_t idx = chunk_next + trv_rank(need);
           if ((fl & F_HAS) == 0u && idx < chunk_end) {
             RayIn ray;
-            fetch(idx, ray);
+            fetch(ws.entries != nullptr ? ws.entries[idx] : idx, ray);
             // a negative tmax marks an entry that traces nothing
             fl = (ray.tmax < 0.0f) ? F_HAS : (F_HAS | F_WALK);
             t = ray.tmax;
@@ -616,7 +643,17 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         }
         if (exhausted && __ballot((fl & F_HAS) != 0u) == 0ull) break;
       }
+#ifdef MIRT_PHASE_TIMING
+      // service-point time, all of it and the part spent with at most 4 / 16 lanes walking
+      MIRT_PH_ADD(14, MIRT_PH_NOW() - ph_sp0);
+      if (n_walking <= 4) MIRT_PH_ADD(11, MIRT_PH_NOW() - ph_sp0);
+      else if (n_walking <= 16) MIRT_PH_ADD(2, MIRT_PH_NOW() - ph_sp0);
+#endif
     }
+#ifdef MIRT_PHASE_TIMING
+    const unsigned long long ph_st0 = MIRT_PH_NOW();
+    const int ph_nw = __popcll(__ballot((fl & F_WALK) != 0u));
+#endif
 
     // =============================================================== steps
     // One node for every lane that can move (blasFirstHit / tlasFirstHit,
@@ -646,7 +683,17 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         const bool wrapped = cur == 0u;
         fl = (fl & ~(F_WRAP | F_HOLD)) | (wrapped ? F_WRAP : 0u) | ((leaf_hit || wrapped) ? F_HOLD : 0u);
       }
+#ifdef MIRT_PHASE_TIMING
+      if (ph_nw <= 4) MIRT_PH_COUNT(9);
+      else if (ph_nw <= 16) MIRT_PH_COUNT(12);
+#endif
     }
+#ifdef MIRT_PHASE_TIMING
+    // step-loop time, all of it and the part spent with at most 4 / 16 lanes walking
+    MIRT_PH_ADD(15, MIRT_PH_NOW() - ph_st0);
+    if (ph_nw <= 4) MIRT_PH_ADD(10, MIRT_PH_NOW() - ph_st0);
+    else if (ph_nw <= 16) MIRT_PH_ADD(13, MIRT_PH_NOW() - ph_st0);
+#endif
   }
   MIRT_PH_FLUSH(ws.phase);
 }

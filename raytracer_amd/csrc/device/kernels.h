@@ -32,8 +32,8 @@ enum StatId {
   S_EXT_TLAS, S_EXT_INST, S_EXT_BLAS, S_EXT_TRI, S_CON_TLAS, S_CON_INST, S_CON_BLAS, S_CON_TRI,
   S_EXT_TRI_LDS, S_EXT_TRI_MEM, S_CON_TRI_LDS, S_CON_TRI_MEM,  // whole-wave scans, by where they read their triangles
   S_OVERFLOW,  // samples whose add would have wrapped a 32-bit radiance sum (the sum saturates instead)
-  S_PHASE0,  // eight words written only by diagnostic builds (-DMIRT_PHASE_TIMING)
-  S_COUNT = S_PHASE0 + 8
+  S_PHASE0,  // sixteen words written only by diagnostic builds (-DMIRT_PHASE_TIMING)
+  S_COUNT = S_PHASE0 + 16
 };
 
 struct DState {

@@ -422,8 +422,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
   const uint32_t count = st.qcount[Q_EXT0 + par];
   LaneCounts lc;
 
-  auto fetch = [&](uint32_t idx, RayIn &r) {
-    const uint32_t slot = ext[idx];
+  auto fetch = [&](uint32_t slot, RayIn &r) {
     load_ray(st.ray, slot, r.pos, r.dir, r.last_inst, r.last_prim);
     r.tmax = FLT_MAX;
     r.payload = slot;
@@ -435,7 +434,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
       h4[0] = make_float4(best.u, best.v, __uint_as_float(best.prim), __uint_as_float(found ? best.inst : kMissInst));
     }
   };
-  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, &st.stats[S_PHASE0]}, lc, fetch, finish);
+  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, ext, &st.stats[S_PHASE0]}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
   if (COUNT) flush_wave_scan_counts(st.stats, S_EXT_TRI_LDS, lc);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
@@ -919,7 +918,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_trace(DScene sc, const DRay *rays, const fl
     reinterpret_cast<float4 *>(out)[idx] =
         make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
   };
-  trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr}, lc, fetch, finish);
+  trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(counts5, 1, lc);
   if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counts5[0], (unsigned long long)n);
 }

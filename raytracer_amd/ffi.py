@@ -133,7 +133,7 @@ class Stats(C.Structure):
                 ("extend_tri_wave_lds", C.c_uint64), ("extend_tri_wave_mem", C.c_uint64),
                 ("connect_tri_wave_lds", C.c_uint64), ("connect_tri_wave_mem", C.c_uint64),
                 ("overflowed_sums", C.c_uint64),
-                ("engine_phase", C.c_uint64 * 8)]
+                ("engine_phase", C.c_uint64 * 16)]
 
 
 class ConfigInfo(C.Structure):

@@ -90,7 +90,7 @@ pub struct MirtStats {
     pub extend_tri_wave_lds: u64,  pub extend_tri_wave_mem: u64,
     pub connect_tri_wave_lds: u64, pub connect_tri_wave_mem: u64,
     pub overflowed_sums: u64,
-    pub engine_phase: [u64; 8],
+    pub engine_phase: [u64; 16],
 }
 
 extern "C" {
