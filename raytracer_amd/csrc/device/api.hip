@@ -725,10 +725,32 @@ static int upload_geometry(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
       memcpy(blk + 2048u + lane * 4u, &t.e2z, 4);
     }
   }
-  // LDS leaf cache: the biggest scanned leaves first, as long as their vertices
-  // and index rows fit the image.
+  // LDS leaf cache: the biggest scanned leaves first, as long as they fit the image —
+  // direct form: a copy of their scan blocks;
   std::vector<uint4> cache_image;
-  {
+  if (kLeafCacheDirect) {
+    std::vector<const ScanLeaf *> order;
+    for (const ScanLeaf &sl : scan_leaves) order.push_back(&sl);
+    std::stable_sort(order.begin(), order.end(), [](const ScanLeaf *a, const ScanLeaf *b) { return a->count > b->count; });
+    size_t at = 0;
+    std::vector<std::pair<const ScanLeaf *, size_t>> taken;
+    for (const ScanLeaf *sl : order) {
+      const size_t bytes = (size_t)((sl->count + 63u) / 64u) * kScanBlockBytes;
+      if (at + bytes > kLeafCacheBytes) continue;
+      taken.push_back({sl, at});
+      at += bytes;
+    }
+    cache_image.assign(at / 16u, uint4{0u, 0u, 0u, 0u});
+    static_assert(kScanBlockBytes % 16u == 0u, "scan blocks are whole 16-byte words");
+    for (const auto &tk : taken) {
+      const ScanLeaf *sl = tk.first;
+      const size_t bytes = (size_t)((sl->count + 63u) / 64u) * kScanBlockBytes;
+      memcpy(reinterpret_cast<unsigned char *>(cache_image.data()) + tk.second,
+             geo.get() + scan_off + sl->block * (size_t)kScanBlockBytes, bytes);
+      tris[sl->first_tri].e2w = (uint32_t)tk.second + 1u;
+    }
+  } else {
+    // indexed form: their unique vertices and index rows
     std::vector<const ScanLeaf *> order;
     for (const ScanLeaf &sl : scan_leaves) order.push_back(&sl);
     std::stable_sort(order.begin(), order.end(), [](const ScanLeaf *a, const ScanLeaf *b) { return a->count > b->count; });

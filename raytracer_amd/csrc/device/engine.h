@@ -193,7 +193,7 @@ struct WorkSource {
 #endif
 // Threads per block of every kernel built on the engine.  One 1024-thread block
 // per CU (four waves per SIMD, which is what 97 registers per lane allow): every
-// wave of the CU shares one copy of the leaf cache, up to 64 KB of LDS.
+// wave of the CU shares one copy of the leaf cache, up to kLeafCacheBytes of LDS.
 constexpr uint32_t kEngineBlock = MIRT_ENGINE_BLOCK;
 // blocks below 512 threads would need a copy of the leaf cache each and go without
 constexpr uint32_t kLeafCacheWords16 = kEngineBlock >= 512u ? kLeafCacheBytes / 16u : 0u;
@@ -384,7 +384,17 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             return false;
           };
           const uint32_t ocached = kLeafCacheWords16 != 0u ? geo_load4(geo, otbase + ostart * 48u + 44u) : 0u;
-          if (ocached != 0u) {
+          if (ocached != 0u && kLeafCacheDirect) {
+            // the leaf's scan blocks are in LDS: the same three planes as in memory
+            const unsigned char *blk = reinterpret_cast<const unsigned char *>(s_cache) + (ocached - 1u) + lane * 16u;
+            for (uint32_t k = lane; k < ocount; k += 64u, blk += kScanBlockBytes) {
+              const uint32_t p = ostart + k;
+              if (p == oskip) continue;
+              const float4 a0 = *reinterpret_cast<const float4 *>(blk), a1 = *reinterpret_cast<const float4 *>(blk + 1024u);
+              const float a2 = *reinterpret_cast<const float *>(blk + 2048u - lane * 12u);
+              if (consider(p, V3(a0.x, a0.y, a0.z), V3(a0.w, a1.x, a1.y), V3(a1.z, a1.w, a2))) break;
+            }
+          } else if (ocached != 0u) {
             // the leaf is in LDS: three 16-bit vertex numbers per triangle, e1 and e2 rebuilt
             // with the subtractions the upload does for DTri
             const uint2 *rows = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(s_cache) + (ocached - 1u));

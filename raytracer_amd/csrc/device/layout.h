@@ -55,7 +55,7 @@ struct DTri {
   float e1x, e1y, e1z;
   uint32_t e1w;  // first triangle of a leaf the whole wave scans: byte offset of its scan blocks
   float e2x, e2y, e2z;
-  uint32_t e2w;  // first triangle of a leaf held in the LDS leaf cache: byte offset of its index array in the image + 1
+  uint32_t e2w;  // first triangle of a leaf held in the LDS leaf cache: byte offset of its blocks / index rows in the image + 1
 };
 
 // Leaves with kScanLeafMin or more triangles are tested by a whole wave, 64
@@ -71,12 +71,27 @@ constexpr uint32_t kScanBlockBytes = 2304u;
 // The largest of those leaves are also kept in LDS by the traversal kernels
 // (their blocks would otherwise be streamed from the L2 by every ray that
 // reaches them): one image of at most kLeafCacheBytes, copied into LDS when a
-// block starts.  Image: the unique vertices of the cached leaves (float4 each,
-// w unused), then per leaf one uint2 per triangle holding three 16-bit vertex
-// numbers (x = v0 | v1 << 16, y = v2).  The kernel rebuilds e1 = p1 - p0 and
-// e2 = p2 - p0 with the same f32 subtractions the upload does for DTri.
+// block starts.  Two forms of image:
+//   direct (kLeafCacheDirect)  the leaves' scan blocks as they are in memory, 36 bytes per
+//            triangle: a lane reads its triangle with two 16-byte and one 4-byte LDS read
+//            and tests it at once;
+//   indexed  the unique vertices of the cached leaves (float4 each, w unused), then per
+//            leaf one uint2 per triangle holding three 16-bit vertex numbers (x = v0 |
+//            v1 << 16, y = v2), about 16 bytes per triangle; the kernel rebuilds
+//            e1 = p1 - p0 and e2 = p2 - p0 with the same f32 subtractions the upload
+//            does for DTri.
+// One engine block runs per CU and the CU has 160 KB of LDS, so the direct form
+// gets 128 KB (about 3 600 triangles).
+#ifndef MIRT_LEAF_CACHE_DIRECT
+#define MIRT_LEAF_CACHE_DIRECT 1
+#endif
+constexpr bool kLeafCacheDirect = MIRT_LEAF_CACHE_DIRECT != 0;
 #ifndef MIRT_LEAF_CACHE_KB
+#if MIRT_LEAF_CACHE_DIRECT
+#define MIRT_LEAF_CACHE_KB 128u
+#else
 #define MIRT_LEAF_CACHE_KB 64u
+#endif
 #endif
 constexpr uint32_t kLeafCacheBytes = MIRT_LEAF_CACHE_KB * 1024u;
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
