@@ -87,6 +87,14 @@ def parse():
 RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
 
 
+def device_of(local_rank):
+    """The GPU a rank (or a group member) drives: its local rank, unless MIRT_BENCH_DEVICES lists ordinals
+    ("0,0" rehearses two ranks on a one-GPU box; RCCL refuses two ranks on one device, so that rehearsal also
+    sets MIRT_BENCH_BACKEND=gloo)."""
+    listed = os.environ.get("MIRT_BENCH_DEVICES")
+    return int(listed.split(",")[local_rank]) if listed else local_rank
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -431,7 +439,7 @@ def group_mode(args):
     arrays, info, W, H, src, cam, params = build_workload(args, args.geometry)
     n_paths = W * H * args.paths_per_pixel
     spp_step = args.spp_per_step
-    with pathtracer.PathtracerGroup(list(range(n))) as grp:
+    with pathtracer.PathtracerGroup([device_of(i) for i in range(n)]) as grp:
         grp.upload_scene(arrays)
         grp.create_state(W, H, n_paths, src, params)
         grp.set_camera(cam)
@@ -524,14 +532,18 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device_of(local_rank))
+        backend = os.environ.get("MIRT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_of(local_rank)))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    device = torch.device("cuda", device_of(local_rank))
 
     from raytracer_amd import distributed, pathtracer
 
     arrays, info, W, H, src, cam, params = build_workload(args, args.geometry)
-    pt = pathtracer.Pathtracer(local_rank)
+    pt = pathtracer.Pathtracer(device_of(local_rank))
     pt.upload_scene(arrays)
     if args.mode == "step":
         step_mode(args, pt, info, W, H, src, cam, params, world)
@@ -598,7 +610,7 @@ def main():
         # the second stand-in geometry, after this context has released its 12 GB of path state
         if (world == 1 and args.config == 3 and args.geometry == "knot" and args.mode == "render"
                 and not args.no_secondary and args.width == 0 and args.height == 0):
-            out["secondary"] = secondary_line(args, local_rank)
+            out["secondary"] = secondary_line(args, device_of(local_rank))
         print(json.dumps(out), flush=True)
 
 

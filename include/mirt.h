@@ -527,8 +527,20 @@ int mirt_group_reset_accum(mirt_group *grp);
 /* Render `spp` further samples for every source: member i takes spp / n of
  * them (the first spp % n members one more), all members at once. */
 int mirt_group_render_spp(mirt_group *grp, uint32_t spp);
-/* Member 0 += members 1..n-1, whose accumulators are then cleared. */
+/* Member 0 += members 1..n-1, whose accumulators are then cleared: the
+ * saturating radiance sums, the counts and, with adaptive sampling, the integer
+ * moments. */
 int mirt_group_reduce(mirt_group *grp);
+/* mirt_adapt_update for the group: reduces (as above), flags the converged
+ * sources on member 0 from the totals and gives every member the same flags
+ * and active list, so the next mirt_group_render_spp skips the same sources on
+ * every GPU.  n_active (may be NULL) receives the sources still active. */
+int mirt_group_adapt_update(mirt_group *grp, float rel_threshold, uint32_t min_samples,
+                            uint32_t *n_active);
+/* mirt_scene_update_transforms on every member; device_ms (may be NULL)
+ * receives the slowest member's device time. */
+int mirt_group_scene_update_transforms(mirt_group *grp, const MirtTransform *transforms,
+                                       uint32_t n_transforms, float *device_ms);
 
 /* -------------------------------------------------------------- diagnostics */
 int mirt_stats(mirt_ctx *ctx, MirtStats *out);

@@ -1130,20 +1130,21 @@ int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots
   return MIRT_OK;
 }
 
-int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
-  ENTER(ctx);
-  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
-  if (!ctx->params.adaptive) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: the state was created with adaptive = 0");
-  if (!(rel_threshold >= 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: rel_threshold must be >= 0");
-  const double thr2 = (double)rel_threshold * (double)rel_threshold;
-  launch_adapt_update(launch_cfg(ctx), ctx->st, thr2, min_samples);
-  HIP_TRY(ctx, hipGetLastError());
+// The host half of a convergence pass: with `flags` on the device (set there by k_adapt_update, or uploaded here
+// when `upload` is given: the flags another member of a group decided), the unflagged sources become the
+// ascending active list that spawn_sample draws from.
+static int install_flags(mirt_ctx *ctx, const uint32_t *upload, std::vector<uint32_t> *flags_out, uint32_t *n_active) {
   // Sample numbers already handed out must not come back under the new list:
   // continue behind the highest one used so far.
   unsigned long long handed = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&handed, ctx->st.sample_index, sizeof(handed), hipMemcpyDeviceToHost, ctx->stream));
   std::vector<uint32_t> flags(ctx->st.n_sources), act;
-  HIP_TRY(ctx, hipMemcpyAsync(flags.data(), ctx->st.flags, (size_t)4 * ctx->st.n_sources, hipMemcpyDeviceToHost, ctx->stream));
+  if (upload) {
+    flags.assign(upload, upload + ctx->st.n_sources);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->st.flags, flags.data(), (size_t)4 * ctx->st.n_sources, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(flags.data(), ctx->st.flags, (size_t)4 * ctx->st.n_sources, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev_collect(ctx);
   if (ctx->slots_seeded && ctx->st.n_active != 0u) {  // mirt_step frames in flight: their numbering restarts
@@ -1161,7 +1162,24 @@ int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, 
   }
   ctx->st.n_active = (uint32_t)act.size();
   if (n_active) *n_active = ctx->st.n_active;
+  if (flags_out) flags_out->swap(flags);
   return MIRT_OK;
+}
+
+static int adapt_update_impl(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active,
+                             std::vector<uint32_t> *flags_out) {
+  if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
+  if (!ctx->params.adaptive) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: the state was created with adaptive = 0");
+  if (!(rel_threshold >= 0.0f)) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "adapt_update: rel_threshold must be >= 0");
+  const double thr2 = (double)rel_threshold * (double)rel_threshold;
+  launch_adapt_update(launch_cfg(ctx), ctx->st, thr2, min_samples);
+  HIP_TRY(ctx, hipGetLastError());
+  return install_flags(ctx, nullptr, flags_out, n_active);
+}
+
+int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
+  ENTER(ctx);
+  return adapt_update_impl(ctx, rel_threshold, min_samples, n_active, nullptr);
 }
 
 int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources) {
@@ -1597,6 +1615,7 @@ struct mirt_group {
   uint32_t next_sample = 0;  // the group's sample-number cursor
   // staging for the reduction, on member 0's device: one copy of the accumulators per other member
   std::vector<uint32_t *> tmp_sum4, tmp_count;
+  std::vector<unsigned long long *> tmp_moments;  // adaptive states only
   std::vector<hipEvent_t> copied;  // member i's copies into its staging have been issued up to here
   size_t tmp_sources = 0;
 };
@@ -1626,8 +1645,10 @@ void group_free_staging(mirt_group *g) {
   if (hipSetDevice(g->members[0]->device) != hipSuccess) return;
   for (uint32_t *p : g->tmp_sum4) (void)hipFree(p);
   for (uint32_t *p : g->tmp_count) (void)hipFree(p);
+  for (unsigned long long *p : g->tmp_moments) (void)hipFree(p);
   g->tmp_sum4.clear();
   g->tmp_count.clear();
+  g->tmp_moments.clear();
   g->tmp_sources = 0;
 }
 
@@ -1745,6 +1766,18 @@ int mirt_group_scene_update_instances(mirt_group *g, const MirtSceneDesc *scene)
   return for_members(g, "scene_update_instances", [&](mirt_ctx *c) { return mirt_scene_update_instances(c, scene); });
 }
 
+int mirt_group_scene_update_transforms(mirt_group *g, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) {
+  float worst = 0.0f;
+  const int rc = for_members(g, "scene_update_transforms", [&](mirt_ctx *c) {
+    float ms = 0.0f;
+    const int r = mirt_scene_update_transforms(c, transforms, n_transforms, &ms);
+    if (ms > worst) worst = ms;
+    return r;
+  });
+  if (device_ms) *device_ms = worst;
+  return rc;
+}
+
 int mirt_group_state_create(mirt_group *g, uint32_t width, uint32_t height, uint32_t threads,
                             const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) {
   const int rc = for_members(g, "state_create", [&](mirt_ctx *c) {
@@ -1792,6 +1825,28 @@ int mirt_group_render_spp(mirt_group *g, uint32_t spp) {
   return MIRT_OK;
 }
 
+int mirt_group_adapt_update(mirt_group *g, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
+  if (!g) return MIRT_ERR_INVALID_ARGUMENT;
+  // the totals — sums, counts, moments of every member — on member 0, which decides; the others take its flags
+  int rc = mirt_group_reduce(g);
+  if (rc != MIRT_OK) return rc;
+  mirt_ctx *root = g->members[0];
+  if (hipSetDevice(root->device) != hipSuccess) return gfail(g, MIRT_ERR_HIP, "adapt_update: hipSetDevice");
+  std::vector<uint32_t> flags;
+  uint32_t left = 0;
+  rc = adapt_update_impl(root, rel_threshold, min_samples, &left, &flags);
+  if (rc != MIRT_OK) return gfail(g, rc, std::string("adapt_update: member 0: ") + mirt_last_error(root));
+  for (size_t i = 1; i < g->members.size(); ++i) {
+    mirt_ctx *c = g->members[i];
+    if (hipSetDevice(c->device) != hipSuccess) return gfail(g, MIRT_ERR_HIP, "adapt_update: hipSetDevice");
+    uint32_t theirs = 0;
+    rc = install_flags(c, flags.data(), nullptr, &theirs);
+    if (rc != MIRT_OK) return gfail(g, rc, "adapt_update: member " + std::to_string(i) + ": " + mirt_last_error(c));
+  }
+  if (n_active) *n_active = left;
+  return MIRT_OK;
+}
+
 int mirt_group_reduce(mirt_group *g) {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   mirt_ctx *root = g->members[0];
@@ -1801,6 +1856,10 @@ int mirt_group_reduce(mirt_group *g) {
   for (size_t i = 1; i < n; ++i)
     if (!g->members[i]->have_state || g->members[i]->st.n_sources != ns)
       return gfail(g, MIRT_ERR_NOT_READY, "reduce: member " + std::to_string(i) + " has no state of the same size");
+  const bool with_moments = root->st.moments != nullptr;
+  for (size_t i = 1; i < n; ++i)
+    if ((g->members[i]->st.moments != nullptr) != with_moments)
+      return gfail(g, MIRT_ERR_NOT_READY, "reduce: member " + std::to_string(i) + " differs in adaptive sampling");
   if (n == 1) return MIRT_OK;
 #define GROUP_TRY(expr)                                                                  \
   do {                                                                                   \
@@ -1808,7 +1867,7 @@ int mirt_group_reduce(mirt_group *g) {
     if (_e != hipSuccess) return gfail(g, MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
   GROUP_TRY(hipSetDevice(root->device));
-  if (g->tmp_sources != ns || g->tmp_sum4.size() != n - 1) {
+  if (g->tmp_sources != ns || g->tmp_sum4.size() != n - 1 || (with_moments && g->tmp_moments.size() != n - 1)) {
     group_free_staging(g);
     GROUP_TRY(hipSetDevice(root->device));
     for (size_t i = 1; i < n; ++i) {
@@ -1817,6 +1876,11 @@ int mirt_group_reduce(mirt_group *g) {
       g->tmp_sum4.push_back(a);
       GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&b), ns * 4));
       g->tmp_count.push_back(b);
+      if (with_moments) {
+        unsigned long long *m = nullptr;
+        GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&m), ns * 16));
+        g->tmp_moments.push_back(m);
+      }
     }
     g->tmp_sources = ns;
   }
@@ -1834,15 +1898,19 @@ int mirt_group_reduce(mirt_group *g) {
     GROUP_TRY(hipSetDevice(c->device));
     GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum4[i - 1], root->device, c->st.sum4, c->device, ns * 16, c->stream));
     GROUP_TRY(hipMemcpyPeerAsync(g->tmp_count[i - 1], root->device, c->st.count, c->device, ns * 4, c->stream));
+    if (with_moments)
+      GROUP_TRY(hipMemcpyPeerAsync(g->tmp_moments[i - 1], root->device, c->st.moments, c->device, ns * 16, c->stream));
     GROUP_TRY(hipEventRecord(g->copied[i - 1], c->stream));
     GROUP_TRY(hipMemsetAsync(c->st.sum4, 0, ns * 16, c->stream));
     GROUP_TRY(hipMemsetAsync(c->st.count, 0, ns * 4, c->stream));
+    if (with_moments) GROUP_TRY(hipMemsetAsync(c->st.moments, 0, ns * 16, c->stream));
   }
   GROUP_TRY(hipSetDevice(root->device));
   for (size_t i = 1; i < n; ++i) {
     GROUP_TRY(hipStreamWaitEvent(root->stream, g->copied[i - 1], 0));
     launch_accum_add(launch_cfg(root), root->st.sum4, g->tmp_sum4[i - 1], ns * 4, true);
     launch_accum_add(launch_cfg(root), root->st.count, g->tmp_count[i - 1], ns, false);
+    if (with_moments) launch_accum_add64(launch_cfg(root), root->st.moments, g->tmp_moments[i - 1], ns * 2);
   }
   GROUP_TRY(hipGetLastError());
   GROUP_TRY(hipStreamSynchronize(root->stream));

@@ -126,6 +126,7 @@ void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
 // dst[i] += src[i] for n words (the integer accumulators of another context)
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n, bool saturate);
+void launch_accum_add64(const LaunchCfg &cfg, unsigned long long *dst, const unsigned long long *src, size_t n);
 void launch_init_slots(const LaunchCfg &cfg, const DState &st);
 // frame 0 of a render call: the first min(slots, sample_limit) samples spawned into slots 0.. (no terminate queue pass)
 void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);

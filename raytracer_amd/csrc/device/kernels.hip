@@ -857,6 +857,13 @@ __global__ __launch_bounds__(256) void k_accum_add(uint32_t *__restrict__ dst, c
   }
 }
 
+// dst += src over 64-bit words (the integer moments of adaptive sampling)
+__global__ __launch_bounds__(256) void k_accum_add64(unsigned long long *__restrict__ dst,
+                                                     const unsigned long long *__restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 // --------------------------------------------------------------- resolve
 
 __device__ __forceinline__ float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
@@ -1019,6 +1026,11 @@ void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, 
   const dim3 grid((unsigned)((threads + 255u) / 256u));
   if (saturate) hipLaunchKernelGGL(k_accum_add<true>, grid, dim3(256), 0, cfg.stream, dst, src, n);
   else hipLaunchKernelGGL(k_accum_add<false>, grid, dim3(256), 0, cfg.stream, dst, src, n);
+}
+
+void launch_accum_add64(const LaunchCfg &cfg, unsigned long long *dst, const unsigned long long *src, size_t n) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_accum_add64, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, cfg.stream, dst, src, n);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {

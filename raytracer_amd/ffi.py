@@ -242,6 +242,7 @@ DEVICE_SYMBOLS = [
     "mirt_group_create", "mirt_group_destroy", "mirt_group_size", "mirt_group_member", "mirt_group_last_error",
     "mirt_group_scene_upload", "mirt_group_scene_update_instances", "mirt_group_state_create",
     "mirt_group_camera_set", "mirt_group_reset_accum", "mirt_group_render_spp", "mirt_group_reduce",
+    "mirt_group_adapt_update", "mirt_group_scene_update_transforms",
 ]
 
 
@@ -308,5 +309,7 @@ def device_lib():
         L.mirt_group_reset_accum.argtypes = [vp]
         L.mirt_group_render_spp.argtypes = [vp, u32]
         L.mirt_group_reduce.argtypes = [vp]
+        L.mirt_group_adapt_update.argtypes = [vp, C.c_float, u32, C.POINTER(u32)]
+        L.mirt_group_scene_update_transforms.argtypes = [vp, vp, u32, C.POINTER(C.c_float)]
         _device = L
     return _device

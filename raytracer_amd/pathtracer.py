@@ -347,6 +347,19 @@ class PathtracerGroup:
     def reduce(self):
         self._check(self._L.mirt_group_reduce(self._g), "mirt_group_reduce")
 
+    def adapt_update(self, rel_threshold, min_samples):
+        """Reduce, flag converged sources from the totals, same flags on every member; returns the sources still active."""
+        n = C.c_uint32()
+        self._check(self._L.mirt_group_adapt_update(self._g, rel_threshold, min_samples, C.byref(n)), "mirt_group_adapt_update")
+        return n.value
+
+    def update_transforms(self, transforms):
+        t = np.ascontiguousarray(transforms, ffi.Transform)
+        ms = C.c_float()
+        self._check(self._L.mirt_group_scene_update_transforms(self._g, t.ctypes.data, len(t), C.byref(ms)),
+                    "mirt_group_scene_update_transforms")
+        return ms.value
+
     def read_accum(self):
         return self.members[0].read_accum()
 

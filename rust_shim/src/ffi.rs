@@ -165,6 +165,9 @@ extern "C" {
     pub fn mirt_group_reset_accum(grp: *mut mirt_group) -> c_int;
     pub fn mirt_group_render_spp(grp: *mut mirt_group, spp: u32) -> c_int;
     pub fn mirt_group_reduce(grp: *mut mirt_group) -> c_int;
+    pub fn mirt_group_adapt_update(grp: *mut mirt_group, rel_threshold: f32, min_samples: u32, n_active: *mut u32) -> c_int;
+    pub fn mirt_group_scene_update_transforms(grp: *mut mirt_group, transforms: *const crate::transform::Transform,
+                                              n_transforms: u32, device_ms: *mut f32) -> c_int;
     // diagnostics
     pub fn mirt_stats(ctx: *mut mirt_ctx, out: *mut MirtStats) -> c_int;
     pub fn mirt_stats_reset(ctx: *mut mirt_ctx) -> c_int;

@@ -322,3 +322,31 @@ def test_transforms_only_update_refuses_a_tlas_that_leaves_instances_out(pt):
     full["transforms"] = moved
     full["tlas_nodes"], full["tlas_to_instances"], _ = pt.build_tlas(aabbs, moved, arrays["instances"])
     assert hits_equal(pt.trace_closest(rays), po.Scene(full).trace_closest(rays))
+
+
+def test_group_transforms_only_update_reaches_every_member():
+    """mirt_group_scene_update_transforms: the device-side TLAS rebuild on every member of a group."""
+    from conftest import hits_equal, random_rays
+    from oracle import pyoracle as po
+    s = host.Scene()
+    cube = s.load_cube()
+    mat = s.add_material(host.make_material())
+    for i in range(9):
+        s.spawn(host.make_transform(translation=(2.5 * (i % 3), 2.5 * (i // 3), 0.0)), mat, cube)
+    arrays = s.bind()
+    s.close()
+    rays = random_rays(5000, 13, centre=(2.5, 2.5, 0.0), spread=7.0)
+    moved = {k: v.copy() for k, v in arrays.items()}
+    moved["transforms"]["translation"][:, 2] += np.linspace(-1.0, 1.0, len(moved["transforms"])).astype("<f4")
+    moved["transforms"]["rotation"][:, 1] += 0.4
+    with pathtracer.PathtracerGroup([0, 0]) as grp:
+        grp.upload_scene(arrays)
+        assert grp.update_transforms(moved["transforms"]) > 0.0
+        roots = moved["blas_nodes"][moved["geometry_offsets"]["blas_node"]]
+        aabbs = np.concatenate([roots["lb"][:, :3], roots["ub"][:, :3]], axis=1)
+        moved["tlas_nodes"], moved["tlas_to_instances"], _ = grp.members[0].build_tlas(aabbs, moved["transforms"], moved["instances"])
+        want = po.Scene(moved).trace_closest(rays)
+        for m in grp.members:
+            assert hits_equal(m.trace_closest(rays), want)
+        with pytest.raises(pathtracer.MirtError, match="member 0"):
+            grp.update_transforms(moved["transforms"][:-1])

@@ -687,6 +687,49 @@ def test_bench_collective_path_with_one_rank():
     assert d["config"]["parallelism"] == "spp split x1"
 
 
+def _bench_line(argv, env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL_BENCH = ["--steps", "2", "--warmup", "1", "--config", "1", "--spp-per-step", "4", "--paths-per-pixel", "2",
+               "--no-cpu-baseline"]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_reduces_across_them():
+    """`python bench.py --gpus 2` as the driver runs it, with no launcher around it: two rank processes, an
+    all-reduce of their accumulators inside the timed region, ONE line from rank 0 that counts both ranks' rays.
+    Both ranks share this box's one GPU here, so the process group is gloo (RCCL refuses two ranks on a device)."""
+    one = _bench_line(["--gpus", "1"] + SMALL_BENCH, {})
+    two = _bench_line(["--gpus", "2"] + SMALL_BENCH, {"MIRT_BENCH_DEVICES": "0,0", "MIRT_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["reduce_ms"] > 0.0
+    assert "one process per GPU" in two["config"]["parallelism"]
+    # weak scaling: every rank renders the samples one GPU renders, on its own sample numbers
+    assert 1.9 * one["rays"] < two["rays"] < 2.1 * one["rays"]
+    assert 0 < two["per_rank_mrays_per_s"]["min"] <= two["per_rank_mrays_per_s"]["max"]
+    assert two["cpu_baseline"] is None and two["roofline"]["launches"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_group_mode_drives_its_members_from_one_process():
+    grp = _bench_line(["--gpus", "2", "--group"] + SMALL_BENCH, {"MIRT_BENCH_DEVICES": "0,0"})
+    one = _bench_line(["--gpus", "1"] + SMALL_BENCH, {})
+    assert grp["n_gpus"] == 2 and "mirt_group" in grp["config"]["parallelism"] and grp["reduce_ms"] > 0.0
+    assert 1.9 * one["rays"] < grp["rays"] < 2.1 * one["rays"]
+
+
 def _comb_scene(leaf_sizes, seed):
     """One instance of a triangle soup under a hand-built comb BVH whose leaves have the
     given sizes: root -> (leaf 0, inner) -> (leaf 1, inner) ... -> (leaf k-2, leaf k-1)."""

@@ -155,3 +155,46 @@ def wcnt_sum_equal(halves, sc, cam, src, W, H, oprm):
     w4, wcnt, wmom = np.zeros(4 * n, "<u4"), np.zeros(n, "<u4"), np.zeros(2 * n, "<u8")
     sc.render_active(cam, src, W, H, oprm, 0, 8, None, w4, wcnt, wmom)
     return np.array_equal(halves[0] + halves[1], wmom)
+
+
+def test_group_adaptive_rounds_flag_the_same_sources_on_every_member(config_scenes):
+    """mirt_group_adapt_update on two contexts (both on device 0 here): every round's samples are split over the
+    members, the reduction brings sums, counts and moments together on member 0, which flags from the totals, and
+    every member takes its flags — round after round the same accumulators, moments, flags and active count as one
+    context rendering all the samples, and (first round) as the oracle."""
+    arrays, info = config_scenes(1)
+    W = H = 128
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    kw = dict(max_bounces=info.max_bounces, seed=info.seed, adaptive=1)
+    prm, oprm = pathtracer.default_params(**kw), po.default_params(**kw)
+    thr, min_samples = np.float32(0.08), 8
+    n = len(src)
+    with pathtracer.Pathtracer(0) as one, pathtracer.PathtracerGroup([0, 0]) as grp:
+        for p in (one, grp):
+            p.upload_scene(arrays)
+            p.create_state(W, H, 6000, src, prm)
+            p.set_camera(cam)
+        history = []
+        for round_no in range(3):
+            one.render_spp(8)
+            grp.render_spp(8)
+            left = one.adapt_update(thr, min_samples)
+            assert grp.adapt_update(thr, min_samples) == left
+            history.append(left)
+            s4, cnt = one.read_accum()
+            g4, gcnt = grp.read_accum()
+            assert np.array_equal(g4, s4) and np.array_equal(gcnt, cnt)
+            assert np.array_equal(grp.members[0].read_moments(), one.read_moments())
+            flags = one.read_flags()
+            for m in grp.members:
+                assert np.array_equal(m.read_flags(), flags)
+            for m in grp.members[1:]:  # cleared by the reduction, moments too
+                assert not m.read_accum()[1].any() and not m.read_moments().any()
+            if round_no == 0:
+                w4, wcnt, wmom = np.zeros(4 * n, "<u4"), np.zeros(n, "<u4"), np.zeros(2 * n, "<u8")
+                wflags = np.zeros(n, "<u4")
+                po.Scene(arrays).render_active(cam, src, W, H, oprm, 0, 8, np.arange(n, dtype="<u4"), w4, wcnt, wmom)
+                assert np.array_equal(g4, w4) and np.array_equal(grp.members[0].read_moments(), wmom)
+                assert po.adapt_update(wcnt, wmom, wflags, thr, min_samples) == left and np.array_equal(flags, wflags)
+        assert 0 < history[-1] < history[0] < n

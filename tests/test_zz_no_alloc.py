@@ -22,6 +22,11 @@ def test_static_workspace_trace_matches_the_allocating_one(config_scenes, small_
             assert hits_equal(got, want)
             assert gc.as_dict() == wc.as_dict()
             assert (want["instance_id"] != ffi.NO_HIT).sum() > len(rays) // 20
+        # ... and against the CPU oracle directly, so that this entry point does not stand on the other one
+        from oracle import pyoracle as po
+        owant, oc = po.Scene(small_knot_scene).trace_closest(small, True)
+        assert hits_equal(got, owant)
+        assert gc.as_dict() == oc.as_dict()
         # without counters, and with the excluded-primitive ids the bounce rays carry
         want = pt.trace_closest(small)
         hit = want["instance_id"] != ffi.NO_HIT
@@ -41,3 +46,28 @@ def test_static_workspace_trace_matches_the_allocating_one(config_scenes, small_
         assert hits_equal(pt.trace_closest_static(random_rays(131072, 8)), pt.trace_closest(random_rays(131072, 8)))
         with pytest.raises(pathtracer.MirtError, match="at most 131072 rays"):
             pt.trace_closest_static(random_rays(131073, 9))
+
+
+def test_two_contexts_on_one_gpu_take_turns_on_the_static_workspace(small_knot_scene):
+    """Every context on a GPU shares that GPU's one array; calls from two threads are serialised by the library
+    (a per-device lock for the whole synchronous call) instead of exchanging rays and results."""
+    import threading
+    sets = [random_rays(90001, 21), random_rays(60007, 22)]
+    with pathtracer.Pathtracer(0) as a, pathtracer.Pathtracer(0) as b:
+        want = []
+        for pt, rays in zip((a, b), sets):
+            pt.upload_scene(small_knot_scene)
+            want.append(pt.trace_closest(rays))
+        bad = []
+
+        def worker(pt, rays, expect):
+            for _ in range(6):
+                if not hits_equal(pt.trace_closest_static(rays), expect):
+                    bad.append(1)
+
+        threads = [threading.Thread(target=worker, args=(pt, rays, w)) for pt, rays, w in zip((a, b), sets, want)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not bad
