@@ -278,7 +278,39 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
         / elapsed / 1e9,
         "node_steps_per_s": nodes / launches / ext_s if ext_s > 0 else 0.0,
         "per_ray": per_ray,
+        "kernels": kernel_table(st, cst),
     }
+
+
+def kernel_table(st, cst):
+    """Every kernel group of the frame priced the same way: algorithmic bytes in the reference's struct sizes
+    (A_extend = 112 B per ray + 64 B per node visit + 76 B per instance visit + 160 B per triangle test; A_connect =
+    52 B per shadow ray + the same per visit, with the any-hit walk's own counts; A_shade = 340 B per shade event;
+    A_spawn = 236 B per spawned sample) / the group's summed HIP-event time / the 8 TB/s HBM peak.  The two
+    traversals are throughput figures in reference units (most of their visits are served from L1 / L2 / LDS); for
+    the streaming kernels — extend epilogue, material / uber shade kernels, sample kernel, which read and write
+    scattered path records once — it is close to real traffic."""
+    rows = []
+
+    def row(name, ms, launches, alg_bytes, note):
+        if not launches:
+            return
+        gbs = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+        rows.append({"kernels": name, "launches": int(launches), "ms_total": ms, "ms_per_launch": ms / launches,
+                     "algorithmic_bytes": alg_bytes, "algorithmic_GBs": gbs,
+                     "frac_of_hbm_peak": gbs / HBM_PEAK_GBS if gbs else None, "note": note})
+
+    row("k_extend", st.extend_ms, st.extend_launches, cst.extend_counts.algorithmic_bytes(112),
+        "closest-hit walk; reference-layout units, not memory traffic")
+    if st.connect_launches:
+        row("k_connect + k_connect_finish", st.connect_ms, st.connect_launches, cst.connect_counts.algorithmic_bytes(52),
+            "any-hit walk of the shadow rays (stops at the first hit) and its epilogue")
+    stream_ms = st.finish_ms + st.shade_ms + st.sample_ms
+    stream_launches = st.finish_launches + st.shade_launches + st.sample_launches
+    names = "k_extend_finish + k_material<1..4> + k_sample" if st.finish_launches else "k_finish_shade_uber + k_sample"
+    row(names, stream_ms, stream_launches, 340.0 * st.shade_events + 236.0 * st.spawned_samples,
+        "streaming kernels: A_shade per shade event + A_spawn per spawned sample")
+    return rows
 
 
 def step_mode(args, pt, info, W, H, src, cam, params, world):

@@ -512,9 +512,13 @@ void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_samp
   if (per_slot) timed_launch(c, K_SAMPLE, [&] { launch_sample_ordered(cfg, c->sc, c->st, fp); });
   else timed_launch(c, K_SAMPLE, [&] { launch_sample(cfg, c->sc, c->st, fp); });
   timed_launch(c, K_EXTEND, [&] { launch_extend(cfg, c->sc, c->st, fp); });
-  if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
+  if (c->params.shade_mode == MIRT_SHADE_CLASSIC && !(c->params.nee && fp.have_lights)) {
+    // no light sampling: nothing sits between the extend epilogue and the material, one launch does both
+    timed_launch(c, K_SHADE, [&] { launch_finish_shade_classic(cfg, c->sc, c->st, fp); });
+  } else if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
+    // light sampling: epilogue with world-space hit records, the connect stage, then one kernel per material
     timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
-    if (c->params.nee && fp.have_lights) timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
+    timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
     timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
   } else {
     // uber shading: the extend epilogue and the shade kernel are one launch
@@ -1122,9 +1126,14 @@ int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_set_rng: the state was created with per-sample streams");
   if (!rng || n_slots != ctx->st.slots) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_set_rng: one uint4 per path slot");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  // the stream state is the third 16-byte word of a slot's 48-byte path record
-  HIP_TRY(ctx, hipMemcpy2D(reinterpret_cast<unsigned char *>(ctx->st.path) + 32, sizeof(DPath), rng, 16, 16, n_slots,
+  // the stream state is the third 16-byte quarter of a slot's path record: the third plane, or bytes 32..47 of
+  // every 48-byte record
+  if (kPathPlanes)
+    HIP_TRY(ctx, hipMemcpy(reinterpret_cast<unsigned char *>(ctx->st.path) + (size_t)32 * n_slots, rng, (size_t)16 * n_slots,
                            hipMemcpyHostToDevice));
+  else
+    HIP_TRY(ctx, hipMemcpy2D(reinterpret_cast<unsigned char *>(ctx->st.path) + 32, sizeof(DPath), rng, 16, 16, n_slots,
+                             hipMemcpyHostToDevice));
   ctx->rng_seeded = true;
   ctx->slots_seeded = false;  // in-flight paths are dropped
   return MIRT_OK;

@@ -23,6 +23,7 @@
 #include <float.h>
 
 #include "device_util.h"
+#include "sample_stage.h"
 
 namespace mirt {
 
@@ -44,15 +45,14 @@ struct SlotIn {
 // with only s.pa loaded.
 template <bool RAW>
 __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, uint32_t slot, SlotIn &s) {
-  const float4 *p4 = reinterpret_cast<const float4 *>(st.path + slot);
-  s.pa = p4[0];
+  s.pa = path_q(st, slot, 0u);
   if (RAW) {
     const uint32_t bounces = __float_as_uint(s.pa.w) - 1u;
     s.pa.w = __uint_as_float(bounces);
     if (bounces == 0u) return false;
   }
-  s.pb = p4[1];
-  s.rng = load_rng(st.path + slot);
+  s.pb = path_q(st, slot, 1u);
+  s.rng = load_rng(st, slot);
   v3 rpos;
   uint32_t li, lp;
   load_ray(st.ray, slot, rpos, s.rdir, li, lp);
@@ -85,10 +85,9 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
 }
 
 __device__ __forceinline__ void store_slot(const DState &st, uint32_t slot, const SlotIn &s, v3 new_pos, v3 new_dir) {
-  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
-  p4[0] = s.pa;
-  p4[1] = s.pb;
-  store_rng(st.path + slot, s.rng);
+  path_q(st, slot, 0u) = s.pa;
+  path_q(st, slot, 1u) = s.pb;
+  store_rng(st, slot, s.rng);
   // origins are offset instead of excluding the primitive just hit
   store_ray(st.ray, slot, new_pos, new_dir, kNoPrim, kNoPrim);
 }
@@ -126,7 +125,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
     const float sgn = (inst_ff >> 31) != 0u ? 1.0f : -1.0f;
     const v3 nf = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
     const v3 orig = add3(V3(ha.x, ha.y, ha.z), scale3(nf, 1e-3f));
-    Rng rng = load_rng(st.path + slot);
+    Rng rng = load_rng(st, slot);
     // light instance and face (two draws), then a point on the face (two draws)
     const float r1 = rng_next(rng);
     const float r2 = rng_next(rng);
@@ -147,7 +146,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
       a = 1.0f - a;
       b = 1.0f - b;
     }
-    store_rng(st.path + slot, rng);
+    store_rng(st, slot, rng);
     if (sc.tri_uv != nullptr) {
       // scenes with textures: where on which light triangle the sample lies rides to k_connect_finish
       // in the ray record's origin, which nothing reads between the traversal and the material kernel
@@ -247,21 +246,138 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
   }
 }
 
+// One shade event of material kind KIND for the slot whose state is in `s` (process_material and the four
+// material files of shaders/archive): radiance, throughput and stream state are updated in `s`, the bounce ray
+// comes back in new_pos / new_dir.  Returns whether the path goes on.  `use_shadow`: the connect stage ran and
+// left the slot's ShadowData (light sampling).
+template <int KIND>
+__device__ __forceinline__ bool shade_material(const DScene &sc, const DState &st, uint32_t slot, SlotIn &s, bool use_shadow,
+                                               v3 &new_pos, v3 &new_dir) {
+  const DInst *inst = &sc.inst[s.inst];
+  new_pos = s.hpos;
+  new_dir = s.rdir;
+  bool alive = false;
+  v3 thr = V3(s.pb.x, s.pb.y, s.pb.z), rad = V3(s.pa.x, s.pa.y, s.pa.z);
+  // the instance's live material may name a texture: it multiplies this kernel's albedo
+  // (the emissive texture for the emissive kernel, the colour texture for the others)
+  v3 texel = V3(1.0f, 1.0f, 1.0f);
+  if (sc.tri_uv != nullptr) {
+    const uint32_t tex = sc.mat[inst->material].tex[KIND == MIRT_MAT_EMISSIVE ? 1 : 0];
+    if (tex != 0u) texel = tex_sample(sc, tex, s.tu, s.tv);
+  }
+  if (KIND == MIRT_MAT_LAMBERTIAN) {
+    // process_material<LambertianData> (archive/material.slang:17-139,
+    // archive/lambertian.slang:26-35)
+    const float *ad = sc.lambertian + 4 * (size_t)inst->kind_data;
+    const v3 albedo = V3(ad[0] * texel.x, ad[1] * texel.y, ad[2] * texel.z);
+    const v3 nf = s.hn;
+    const v3 wo = neg3(s.rdir);
+    // scatter draws three values but stores the state after the second
+    const float a = rng_next(s.rng);
+    const float b = rng_next(s.rng);
+    Rng tmp = s.rng;
+    const float c = rng_next(tmp);
+    const v3 scv = add3(nf, rand_unit_sphere(a, b, c));
+    const v3 wi = normalize3(length3(scv) < 1e-6f ? nf : scv);
+    const float scatter_prob = lambert_pdf(wi, nf);
+    (void)rng_next(s.rng);  // archive/material.slang:91-92
+    alive = true;
+    if (use_shadow) {
+      const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
+      const float4 s0 = sh4[0], s1 = sh4[1];
+      const float sprob = s0.w;
+      if (sprob > 0.0f) {
+        const v3 sdir = V3(s0.x, s0.y, s0.z);
+        float shadow_weight = 1.0f * sprob;
+        shadow_weight /= (1.0f * sprob + 1.0f * lambert_pdf(sdir, nf));
+        v3 contrib = thr;
+        contrib = mul3(contrib, lambert_brdf(albedo, sdir, wo, nf));
+        contrib = scale3(contrib, dot3(sdir, nf));
+        contrib = scale3(contrib, shadow_weight);
+        const float dl = 1.0f * sprob;
+        contrib = V3(contrib.x / dl, contrib.y / dl, contrib.z / dl);
+        rad = add3(rad, mul3(V3(s1.x, s1.y, s1.z), contrib));
+      }
+    }
+    if (scatter_prob > 0.0f) {
+      float scatter_weight = 1.0f * scatter_prob;
+      scatter_weight /= 1.0f * scatter_prob + 1.0f * 0.0f;
+      thr = mul3(thr, lambert_brdf(albedo, wi, wo, nf));
+      thr = scale3(thr, dot3(wi, nf));
+      thr = scale3(thr, scatter_weight);
+      const float ds = 1.0f * scatter_prob;
+      thr = V3(thr.x / ds, thr.y / ds, thr.z / ds);
+    } else {
+      thr = scale3(thr, 0.0f);
+      alive = false;
+    }
+    new_pos = add3(s.hpos, scale3(nf, 1e-3f));
+    new_dir = wi;
+  } else if (KIND == MIRT_MAT_METALLIC) {
+    // archive/metallic.slang:65-96
+    const float *md = sc.metallic + 8 * (size_t)inst->kind_data;
+    const v3 nf = s.hn;
+    new_pos = add3(s.hpos, scale3(nf, 0.005f));
+    thr = mul3(thr, V3(md[0] * texel.x, md[1] * texel.y, md[2] * texel.z));
+    const v3 dir = s.rdir;
+    const v3 reflected = sub3(dir, scale3(nf, 2.0f * dot3(dir, nf)));
+    const float a = rng_next(s.rng), b = rng_next(s.rng), c = rng_next(s.rng);
+    const v3 scv = add3(reflected, scale3(rand_unit_sphere(a, b, c), md[4]));
+    new_dir = normalize3(length3(scv) < 1e-2f ? reflected : scv);
+    alive = true;
+  } else if (KIND == MIRT_MAT_DIELECTRIC) {
+    // archive/dielectric.slang:34-95
+    const float *dd = sc.dielectric + 8 * (size_t)inst->kind_data;
+    const v3 nf = s.hn;
+    const float ir = dd[4];
+    const float ratio = s.ff != 0u ? (1.0f / ir) : ir;
+    const v3 ud = normalize3(s.rdir);
+    const float cos_theta = fmin_nn(-dot3(ud, nf), 1.0f);
+    const float sin_theta = __builtin_sqrtf(fmax_nn(0.0f, 1.0f - pow2f(cos_theta)));
+    const bool cannot_refract = ratio * sin_theta > 1.0f;
+    float r0 = (1.0f - ratio) / (1.0f + ratio);
+    r0 *= r0;
+    const float reflectance = r0 + (1.0f - r0) * pow5f(1.0f - cos_theta);
+    const float rnd = rng_next(s.rng);
+    v3 scv;
+    if (cannot_refract || reflectance > rnd) {
+      scv = sub3(ud, scale3(nf, 2.0f * dot3(ud, nf)));
+      new_pos = add3(s.hpos, scale3(nf, 1e-4f));
+    } else {
+      const float ct = fmin_nn(-dot3(ud, nf), 1.0f);
+      const v3 perp = scale3(add3(ud, scale3(nf, ct)), ratio);
+      const float k = 1.0f - dot3(perp, perp);
+      const v3 par_v = scale3(nf, -__builtin_sqrtf(fmax_nn(k, 0.0f)));
+      scv = add3(perp, par_v);
+      new_pos = sub3(s.hpos, scale3(nf, 1e-4f));
+    }
+    thr = mul3(thr, V3(dd[0] * texel.x, dd[1] * texel.y, dd[2] * texel.z));
+    new_dir = normalize3(scv);
+    alive = true;
+  } else {
+    // archive/emissive.slang:42-59
+    const float *ed = sc.emissive + 4 * (size_t)inst->kind_data;
+    rad = add3(rad, mul3(V3(ed[0] * texel.x, ed[1] * texel.y, ed[2] * texel.z), thr));
+    alive = false;
+  }
+  s.pa.x = rad.x; s.pa.y = rad.y; s.pa.z = rad.z;
+  s.pb.x = thr.x; s.pb.y = thr.y; s.pb.z = thr.z;
+  return alive;
+}
+
 // ------------------------------------------------------- material kernels
 // Common frame of the four kernels: pop `queue`, shade, push to the next
 // frame's extension queue (alive) or terminate queue.
 #ifndef MIRT_MATERIAL_WAVES
 #define MIRT_MATERIAL_WAVES 4
 #endif
-template <int KIND, bool RAW>
+template <int KIND>
 __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(DScene sc, DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
   const uint32_t par = fp.frame & 1u;
   const int q = Q_LAMBERTIAN - 1 + KIND;
   const uint32_t *mq = st.qdata[q];
   const uint32_t count = st.qcount[q];
-  const bool use_shadow = !RAW;  // light sampling on: the connect kernel ran and left ShadowData
-  unsigned long long unshaded = 0;  // entries that were out of bounces (RAW only)
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
@@ -270,131 +386,124 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
     if (active) {
       slot = mq[i];
       SlotIn s;
-      if (!load_slot<RAW>(sc, st, slot, s)) {
-        reinterpret_cast<float4 *>(st.path + slot)[0] = s.pa;  // out of bounces: the path ends unshaded
-        unshaded++;
-      } else {
-      const DInst *inst = &sc.inst[s.inst];
-      v3 new_pos = s.hpos, new_dir = s.rdir;
-      v3 thr = V3(s.pb.x, s.pb.y, s.pb.z), rad = V3(s.pa.x, s.pa.y, s.pa.z);
-      // the instance's live material may name a texture: it multiplies this kernel's albedo
-      // (the emissive texture for the emissive kernel, the colour texture for the others)
-      v3 texel = V3(1.0f, 1.0f, 1.0f);
-      if (sc.tri_uv != nullptr) {
-        const uint32_t tex = sc.mat[inst->material].tex[KIND == MIRT_MAT_EMISSIVE ? 1 : 0];
-        if (tex != 0u) texel = tex_sample(sc, tex, s.tu, s.tv);
-      }
-      if (KIND == MIRT_MAT_LAMBERTIAN) {
-        // process_material<LambertianData> (archive/material.slang:17-139,
-        // archive/lambertian.slang:26-35)
-        const float *ad = sc.lambertian + 4 * (size_t)inst->kind_data;
-        const v3 albedo = V3(ad[0] * texel.x, ad[1] * texel.y, ad[2] * texel.z);
-        const v3 nf = s.hn;
-        const v3 wo = neg3(s.rdir);
-        // scatter draws three values but stores the state after the second
-        const float a = rng_next(s.rng);
-        const float b = rng_next(s.rng);
-        Rng tmp = s.rng;
-        const float c = rng_next(tmp);
-        const v3 scv = add3(nf, rand_unit_sphere(a, b, c));
-        const v3 wi = normalize3(length3(scv) < 1e-6f ? nf : scv);
-        const float scatter_prob = lambert_pdf(wi, nf);
-        (void)rng_next(s.rng);  // archive/material.slang:91-92
-        alive = true;
-        if (use_shadow) {
-          const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
-          const float4 s0 = sh4[0], s1 = sh4[1];
-          const float sprob = s0.w;
-          if (sprob > 0.0f) {
-            const v3 sdir = V3(s0.x, s0.y, s0.z);
-            float shadow_weight = 1.0f * sprob;
-            shadow_weight /= (1.0f * sprob + 1.0f * lambert_pdf(sdir, nf));
-            v3 contrib = thr;
-            contrib = mul3(contrib, lambert_brdf(albedo, sdir, wo, nf));
-            contrib = scale3(contrib, dot3(sdir, nf));
-            contrib = scale3(contrib, shadow_weight);
-            const float dl = 1.0f * sprob;
-            contrib = V3(contrib.x / dl, contrib.y / dl, contrib.z / dl);
-            rad = add3(rad, mul3(V3(s1.x, s1.y, s1.z), contrib));
-          }
-        }
-        if (scatter_prob > 0.0f) {
-          float scatter_weight = 1.0f * scatter_prob;
-          scatter_weight /= 1.0f * scatter_prob + 1.0f * 0.0f;
-          thr = mul3(thr, lambert_brdf(albedo, wi, wo, nf));
-          thr = scale3(thr, dot3(wi, nf));
-          thr = scale3(thr, scatter_weight);
-          const float ds = 1.0f * scatter_prob;
-          thr = V3(thr.x / ds, thr.y / ds, thr.z / ds);
-        } else {
-          thr = scale3(thr, 0.0f);
-          alive = false;
-        }
-        new_pos = add3(s.hpos, scale3(nf, 1e-3f));
-        new_dir = wi;
-      } else if (KIND == MIRT_MAT_METALLIC) {
-        // archive/metallic.slang:65-96
-        const float *md = sc.metallic + 8 * (size_t)inst->kind_data;
-        const v3 nf = s.hn;
-        new_pos = add3(s.hpos, scale3(nf, 0.005f));
-        thr = mul3(thr, V3(md[0] * texel.x, md[1] * texel.y, md[2] * texel.z));
-        const v3 dir = s.rdir;
-        const v3 reflected = sub3(dir, scale3(nf, 2.0f * dot3(dir, nf)));
-        const float a = rng_next(s.rng), b = rng_next(s.rng), c = rng_next(s.rng);
-        const v3 scv = add3(reflected, scale3(rand_unit_sphere(a, b, c), md[4]));
-        new_dir = normalize3(length3(scv) < 1e-2f ? reflected : scv);
-        alive = true;
-      } else if (KIND == MIRT_MAT_DIELECTRIC) {
-        // archive/dielectric.slang:34-95
-        const float *dd = sc.dielectric + 8 * (size_t)inst->kind_data;
-        const v3 nf = s.hn;
-        const float ir = dd[4];
-        const float ratio = s.ff != 0u ? (1.0f / ir) : ir;
-        const v3 ud = normalize3(s.rdir);
-        const float cos_theta = fmin_nn(-dot3(ud, nf), 1.0f);
-        const float sin_theta = __builtin_sqrtf(fmax_nn(0.0f, 1.0f - pow2f(cos_theta)));
-        const bool cannot_refract = ratio * sin_theta > 1.0f;
-        float r0 = (1.0f - ratio) / (1.0f + ratio);
-        r0 *= r0;
-        const float reflectance = r0 + (1.0f - r0) * pow5f(1.0f - cos_theta);
-        const float rnd = rng_next(s.rng);
-        v3 scv;
-        if (cannot_refract || reflectance > rnd) {
-          scv = sub3(ud, scale3(nf, 2.0f * dot3(ud, nf)));
-          new_pos = add3(s.hpos, scale3(nf, 1e-4f));
-        } else {
-          const float ct = fmin_nn(-dot3(ud, nf), 1.0f);
-          const v3 perp = scale3(add3(ud, scale3(nf, ct)), ratio);
-          const float k = 1.0f - dot3(perp, perp);
-          const v3 par_v = scale3(nf, -__builtin_sqrtf(fmax_nn(k, 0.0f)));
-          scv = add3(perp, par_v);
-          new_pos = sub3(s.hpos, scale3(nf, 1e-4f));
-        }
-        thr = mul3(thr, V3(dd[0] * texel.x, dd[1] * texel.y, dd[2] * texel.z));
-        new_dir = normalize3(scv);
-        alive = true;
-      } else {
-        // archive/emissive.slang:42-59
-        const float *ed = sc.emissive + 4 * (size_t)inst->kind_data;
-        rad = add3(rad, mul3(V3(ed[0] * texel.x, ed[1] * texel.y, ed[2] * texel.z), thr));
-        alive = false;
-      }
-      s.pa.x = rad.x; s.pa.y = rad.y; s.pa.z = rad.z;
-      s.pb.x = thr.x; s.pb.y = thr.y; s.pb.z = thr.z;
+      (void)load_slot<false>(sc, st, slot, s);
+      v3 new_pos, new_dir;
+      alive = shade_material<KIND>(sc, st, slot, s, true, new_pos, new_dir);  // the connect kernel ran and left ShadowData
       store_slot(st, slot, s, new_pos, new_dir);
-      }
     }
     block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
                 &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)count);
-  if (RAW) {
-    for (int off = 32; off > 0; off >>= 1) unshaded += __shfl_down(unshaded, off);
-    if (lane_id() == 0u && unshaded) atomicAdd(&st.stats[S_SHADE_EVENTS], 0ull - unshaded);
+}
+
+// Per-material shading without light sampling, in ONE pass over the extension queue: extensionMain's epilogue
+// (sky on a miss, the bounce count of archive/extension.slang:94-101) and the hit material's shade event, with
+// the traversal's result and the path record in registers between the two — no routing pass, no material
+// queues, no hit-record round trip.  A wave whose lanes hit different kinds of material runs their branches one
+// after the other; each is a few dozen instructions against the dozen scattered memory requests a slot costs.
+// The four k_material kernels stay for light sampling, where the connect stage sits between the two halves.
+//
+// RESPAWN: a path that ends here — sky, out of bounces, no material, absorbed by its material — is
+// accumulated and its slot takes the render call's next sample at once (as in k_finish_shade_uber<true>).
+template <bool RESPAWN>
+__global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_shade_classic(DScene sc, DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  __shared__ BlockReserve shr;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_EXT0 + par];
+  CamBasis cb;
+  if (RESPAWN) cb = cam_basis(fp.cam);
+  unsigned long long shaded = 0, finished = 0, spawned = 0;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < count;
+    uint32_t slot = 0;
+    bool alive = false;
+    float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // of a path that ends here
+    uint32_t source = kNoSample;
+    if (active) {
+      slot = ext[i];
+      const uint32_t inst = __float_as_uint(reinterpret_cast<const float4 *>(st.hit + slot)[0].w);
+      if (inst == kMissInst) {
+        // rad += throughput * sky
+        float4 pa = path_q(st, slot, 0u);
+        const float4 pb = path_q(st, slot, 1u);
+        const float sky = fp.p.sky_radiance;
+        pa.x = pa.x + pb.x * sky;
+        pa.y = pa.y + pb.y * sky;
+        pa.z = pa.z + pb.z * sky;
+        rad = pa;
+        source = __float_as_uint(pb.w);
+        if (!RESPAWN) path_q(st, slot, 0u) = pa;
+      } else {
+        const uint32_t kind = sc.inst[inst].kind;
+        SlotIn s;
+        if (kind == MIRT_MAT_NONE) {
+          // no material (archive/logic.slang:171-174): the path ends as it is
+          rad = path_q(st, slot, 0u);
+          source = path_w(st, slot, 7u);
+        } else if (!load_slot<true>(sc, st, slot, s)) {
+          // out of bounces: the path ends unshaded
+          rad = s.pa;
+          source = path_w(st, slot, 7u);
+          if (!RESPAWN) path_q(st, slot, 0u) = s.pa;
+        } else {
+          v3 new_pos, new_dir;
+          if (kind == MIRT_MAT_LAMBERTIAN) alive = shade_material<MIRT_MAT_LAMBERTIAN>(sc, st, slot, s, false, new_pos, new_dir);
+          else if (kind == MIRT_MAT_METALLIC) alive = shade_material<MIRT_MAT_METALLIC>(sc, st, slot, s, false, new_pos, new_dir);
+          else if (kind == MIRT_MAT_DIELECTRIC) alive = shade_material<MIRT_MAT_DIELECTRIC>(sc, st, slot, s, false, new_pos, new_dir);
+          else alive = shade_material<MIRT_MAT_EMISSIVE>(sc, st, slot, s, false, new_pos, new_dir);
+          shaded++;
+          rad = s.pa;
+          source = __float_as_uint(s.pb.w);
+          if (alive || !RESPAWN) store_slot(st, slot, s, new_pos, new_dir);
+        }
+      }
+    }
+    if (RESPAWN) {
+      const bool done = active && !alive;
+      if (done) {
+        accumulate_sample(st, fp, source, rad);
+        finished++;
+      }
+      const unsigned long long si = block_reserve(shr, st.sample_index, done);
+      if (done && si < fp.sample_limit) {
+        spawn_sample(st, fp, cb, slot, si);
+        spawned++;
+        alive = true;
+      } else if (done) {
+        path_w(st, slot, 7u) = kNoSample;  // the slot retires
+      }
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
+                  false, slot);
+    } else {
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
+                  &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    shaded += __shfl_down(shaded, off);
+    if (RESPAWN) {
+      finished += __shfl_down(finished, off);
+      spawned += __shfl_down(spawned, off);
+    }
+  }
+  if (lane_id() == 0u) {
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
   }
 }
 
 }  // namespace
+
+void launch_finish_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  if (fp.respawn) hipLaunchKernelGGL((k_finish_shade_classic<true>), stream_grid(cfg, k_finish_shade_classic<true>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_finish_shade_classic<false>), stream_grid(cfg, k_finish_shade_classic<false>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+}
 
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
@@ -407,18 +516,10 @@ void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &
   // the four per-material kernels, one queue each (archive frame order:
   // src/app.rs:402-410 dispatches every material phase each frame)
   const dim3 block(kStreamBlock);
-  if (fp.p.nee && fp.have_lights) {
-    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, false>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN, false>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, false>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC, false>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, false>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC, false>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, false>), stream_grid(cfg, k_material<MIRT_MAT_EMISSIVE, false>), block, 0, cfg.stream, sc, st, fp);
-  } else {
-    // no connect kernel: the material kernels build the hit record from the traversal's raw result
-    hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN, true>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN, true>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC, true>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC, true>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC, true>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC, true>), block, 0, cfg.stream, sc, st, fp);
-    hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE, true>), stream_grid(cfg, k_material<MIRT_MAT_EMISSIVE, true>), block, 0, cfg.stream, sc, st, fp);
-  }
+  hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN>), block, 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC>), block, 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC>), block, 0, cfg.stream, sc, st, fp);
+  hipLaunchKernelGGL((k_material<MIRT_MAT_EMISSIVE>), stream_grid(cfg, k_material<MIRT_MAT_EMISSIVE>), block, 0, cfg.stream, sc, st, fp);
 }
 
 }  // namespace mirt

@@ -151,13 +151,22 @@ __device__ __forceinline__ void store_ray(DRay *rays, uint32_t i, v3 pos, v3 dir
   r4[1] = make_float4(dir.y, dir.z, __uint_as_float(last_inst), __uint_as_float(last_prim));
 }
 
-__device__ __forceinline__ Rng load_rng(const DPath *p) {
-  const float4 r = reinterpret_cast<const float4 *>(p)[2];
+// Quarter k of a slot's path record (DPath: 0 = radiance + bounces, 1 = throughput + source, 2 = stream
+// state) and word w of the record (3 = bounces, 7 = source).  kPathPlanes lays the quarters out as three planes
+// of `slots` float4 each, so that a wave walking consecutive slots reads a contiguous kilobyte per load.
+__device__ __forceinline__ float4 &path_q(const DState &st, uint32_t slot, uint32_t k) {
+  return kPathPlanes ? reinterpret_cast<float4 *>(st.path)[(size_t)k * st.slots + slot]
+                     : reinterpret_cast<float4 *>(st.path + slot)[k];
+}
+__device__ __forceinline__ uint32_t &path_w(const DState &st, uint32_t slot, uint32_t w) {
+  return reinterpret_cast<uint32_t *>(&path_q(st, slot, w >> 2))[w & 3u];
+}
+__device__ __forceinline__ Rng load_rng(const DState &st, uint32_t slot) {
+  const float4 r = path_q(st, slot, 2u);
   return Rng{__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w)};
 }
-__device__ __forceinline__ void store_rng(DPath *p, const Rng &rng) {
-  reinterpret_cast<float4 *>(p)[2] =
-      make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
+__device__ __forceinline__ void store_rng(const DState &st, uint32_t slot, const Rng &rng) {
+  path_q(st, slot, 2u) = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
 }
 
 // The two whole-wave-scan tallies of a lane, to stats[first], stats[first + 1].

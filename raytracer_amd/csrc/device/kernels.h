@@ -123,6 +123,8 @@ void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// per-material shading without light sampling: the extend epilogue and the hit material's shade event in one kernel
+void launch_finish_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);
 // dst[i] += src[i] for n words (the integer accumulators of another context)
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n, bool saturate);

@@ -20,108 +20,13 @@
 
 #include "kernels.h"
 #include "device_util.h"
+#include "sample_stage.h"
 
 namespace mirt {
 
 namespace {
 
 // ---------------------------------------------------------------- sample
-
-// accumulateSample (shaders/sample.slang:35-47).  uint() of a negative or huge
-// float is undefined in the reference; this clamps to [0, 2^32).
-__device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
-  if (__builtin_isnan(rad) || __builtin_isinf(rad)) rad = 0.0f;
-  const float x = rad * scale;
-  if (!(x >= 0.0f)) return 0u;
-  if (x >= 4294967040.0f) return 4294967040u;
-  return (uint32_t)x;
-}
-
-// One channel of a sum.  The reference's InterlockedAdd wraps; here a sum that
-// would pass 2^32 - 1 ends on 2^32 - 1 whatever the order of the adds: an add that
-// wraps is followed by an atomic max with 2^32 - 1, and so is every positive
-// add that comes after it.  Returns true when that happened.
-__device__ __forceinline__ bool add_saturating(uint32_t *p, uint32_t v) {
-  if (v == 0u) return false;
-  const uint32_t old = atomicAdd(p, v);
-  if (old + v >= old) return false;
-  atomicMax(p, 0xFFFFFFFFu);
-  return true;
-}
-
-// accumulateSample's sums (shaders/sample.slang:38-47) for one finished sample
-__device__ __forceinline__ void accumulate_sample(const DState &st, const DFrameParams &fp, uint32_t source, float4 rad) {
-  atomicAdd(&st.count[source], 1u);
-  uint32_t *sum = &st.sum4[4 * (size_t)source];
-  const bool o0 = add_saturating(sum + 0, to_fixed(rad.x, fp.p.fixed_point_scale));
-  const bool o1 = add_saturating(sum + 1, to_fixed(rad.y, fp.p.fixed_point_scale));
-  const bool o2 = add_saturating(sum + 2, to_fixed(rad.z, fp.p.fixed_point_scale));
-  if (o0 || o1 || o2) atomicAdd(&st.stats[S_OVERFLOW], (unsigned long long)((o0 ? 1 : 0) + (o1 ? 1 : 0) + (o2 ? 1 : 0)));
-  if (st.moments != nullptr) {
-    // adaptive sampling: first and second moment of the sample's value y = r + g + b in fixed point,
-    // clamped to 24 bits so that 2^16 squares fit 64 bits — integers, so that sums from several
-    // GPUs add exactly (the reference declares a float4 sample_std for this, shaders/pathtracer.slang:31,
-    // and never writes it)
-    unsigned long long y = (unsigned long long)to_fixed(rad.x, fp.p.fixed_point_scale) +
-                           (unsigned long long)to_fixed(rad.y, fp.p.fixed_point_scale) +
-                           (unsigned long long)to_fixed(rad.z, fp.p.fixed_point_scale);
-    if (y > 0xFFFFFFull) y = 0xFFFFFFull;
-    atomicAdd(&st.moments[2 * (size_t)source], y);
-    atomicAdd(&st.moments[2 * (size_t)source + 1], y * y);
-  }
-}
-
-// camera basis (shaders/sample.slang:87-90)
-struct CamBasis {
-  v3 pos, up, right, top_left;
-  float dx, dy;
-};
-__device__ __forceinline__ CamBasis cam_basis(const MirtCamera &cam) {
-  CamBasis cb;
-  const v3 fwd = V3(cam.forward[0], cam.forward[1], cam.forward[2]);
-  cb.pos = V3(cam.position[0], cam.position[1], cam.position[2]);
-  cb.up = V3(cam.up[0], cam.up[1], cam.up[2]);
-  cb.right = cross3(fwd, cb.up);
-  cb.dx = cam.dims[0];
-  cb.dy = cam.dims[1];
-  cb.top_left = sub3(add3(scale3(fwd, cam.focal_length), scale3(cb.up, cb.dy)), scale3(cb.right, cb.dx));
-  return cb;
-}
-
-// spawnSample (shaders/sample.slang:59-102): sample number `si` of this render
-// call starts in `slot`.
-__device__ __forceinline__ void spawn_sample(const DState &st, const DFrameParams &fp, const CamBasis &cb, uint32_t slot,
-                                             unsigned long long si) {
-  // sample_idx % P (shaders/sample.slang:64-68) over the sources that still take
-  // samples: a source flagged Converged is skipped at spawn
-  // (shaders/archive/logic.slang:113-116) by not being on the list
-  uint32_t source, k;
-  if ((si >> 32) == 0ull) {
-    source = (uint32_t)si % st.n_active;
-    k = (uint32_t)si / st.n_active;
-  } else {
-    source = (uint32_t)(si % st.n_active);
-    k = (uint32_t)(si / st.n_active);
-  }
-  if (st.active != nullptr) source = st.active[source];
-  k += fp.first_sample;
-  const MirtSampleSource src = st.sources[source];
-  // per-sample streams are keyed by (seed, source, sample number); per-slot streams are the
-  // slot's own, seeded by the host and never re-seeded (shaders/random.slang:32-36)
-  Rng rng = fp.p.rng_mode == MIRT_RNG_PER_SLOT ? load_rng(st.path + slot) : rng_init(fp.p.seed, source, k);
-  const float r1 = rng_next(rng);  // x jitter takes the first draw
-  const float r2 = rng_next(rng);
-  const float jx = r1 / (float)st.width, jy = r2 / (float)st.height;
-  const float sy = src.screen_pos[1] + jy, sx = src.screen_pos[0] + jx;
-  const v3 offset =
-      add3(scale3(scale3(scale3(cb.up, -2.0f), cb.dy), sy), scale3(scale3(scale3(cb.right, 2.0f), cb.dx), sx));
-  const v3 dir = normalize3(add3(cb.top_left, offset));
-  float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
-  p4[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(fp.p.max_bounces));
-  p4[1] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(source));
-  p4[2] = make_float4(__uint_as_float(rng.x), __uint_as_float(rng.y), __uint_as_float(rng.z), __uint_as_float(rng.w));
-  store_ray(st.ray, slot, cb.pos, dir, kNoPrim, kNoPrim);
-}
 
 __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams fp) {
   __shared__ BlockPush2 sh;
@@ -148,12 +53,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
     const uint32_t i = base + threadIdx.x;
     const bool active = i < count;
     uint32_t slot = 0;
-    DPath *pp = nullptr;
     if (active) {
       slot = term[i];
-      pp = st.path + slot;
-      const float4 a = reinterpret_cast<const float4 *>(pp)[0];
-      const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
+      const float4 a = path_q(st, slot, 0u);
+      const uint32_t source = path_w(st, slot, 7u);
       if (source != kNoSample) {
         accumulate_sample(st, fp, source, a);
         finished++;
@@ -167,7 +70,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
       spawn_sample(st, fp, cb, slot, si);
       spawned++;
     } else if (active) {
-      reinterpret_cast<uint32_t *>(pp)[7] = kNoSample;  // the slot retires
+      path_w(st, slot, 7u) = kNoSample;  // the slot retires
     }
     block_push2(sh, &st.qcount[Q_EXT0 + par], ext, spawn, nullptr, nullptr, false, slot);
   }
@@ -224,10 +127,9 @@ __global__ __launch_bounds__(kStreamBlock) void k_mark_terminated(DState st, DFr
   unsigned long long finished = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
     const uint32_t slot = term[i];
-    DPath *pp = st.path + slot;
-    const uint32_t source = reinterpret_cast<const uint32_t *>(pp)[7];
+    const uint32_t source = path_w(st, slot, 7u);
     if (source != kNoSample) {
-      accumulate_sample(st, fp, source, reinterpret_cast<const float4 *>(pp)[0]);
+      accumulate_sample(st, fp, source, path_q(st, slot, 0u));
       finished++;
     }
     st.slot_stamp[slot] = fp.stamp;
@@ -350,7 +252,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_ordered_spawn(DState st, DFram
       spawn_sample(st, fp, cb, slot, si);
       ext[ext_base + rank] = slot;  // the spawned slots join the extension queue in slot order
     } else if (ended) {
-      reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+      path_w(st, slot, 7u) = kNoSample;  // the slot retires
     }
     __syncthreads();
   }
@@ -382,7 +284,7 @@ __global__ __launch_bounds__(256) void k_init_slots(DState st) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < st.slots) {
     st.qdata[Q_TERM0][i] = i;
-    reinterpret_cast<uint32_t *>(st.path + i)[7] = kNoSample;
+    path_w(st, i, 7u) = kNoSample;
   }
   if (i < QW_COUNT) st.qcount[i] = i == Q_TERM0 ? st.slots : 0u;
 }
@@ -413,7 +315,6 @@ __global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp)
 // nothing was hit) in its first 16 bytes — for
 // the streaming kernel that follows; keeping the epilogue out of this kernel
 // keeps its registers and instruction footprint small.
-constexpr uint32_t kMissInst = 0xFFFFFFFFu;
 
 template <bool COUNT>
 __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams fp) {
@@ -451,24 +352,18 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
 // accumulated and its slot takes the next sample at once, as in
 // k_finish_shade_uber<true>; paths that end in a material kernel still go
 // through the terminate queue and the sample kernel.
-// RAW (no light sampling): the material kernel is the only reader of the hit
-// record, so it builds the world-space record itself from u, v, t, instance and
-// triangle (finish_hit) and counts the bounce; this kernel only routes.
-template <bool RESPAWN, bool RAW>
+// (Without light sampling this kernel is not used: k_finish_shade_classic does the epilogue and the material
+// in one pass.)
+template <bool RESPAWN>
 __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  // queue 0: terminate (RESPAWN: the next frame's extension queue, for the respawned slot);
-  // 1..5: connect and the four material queues, in QueueId order
+  // a path that ends goes to the terminate queue (RESPAWN: its slot, respawned, to the next frame's extension
+  // queue); a hit goes to the connect queue
   const int q0 = RESPAWN ? Q_EXT0 + (int)(par ^ 1u) : Q_TERM0 + (int)(par ^ 1u);
-  __shared__ BlockPushN<6> sh;
+  __shared__ BlockPush2 sh;
   __shared__ BlockReserve shr;
-  static_assert(Q_LAMBERTIAN == Q_CONNECT + 1 && Q_EMISSIVE == Q_CONNECT + 4, "routes index consecutive queues");
-  uint32_t *const counts[6] = {&st.qcount[q0], &st.qcount[Q_CONNECT], &st.qcount[Q_LAMBERTIAN], &st.qcount[Q_METALLIC],
-                               &st.qcount[Q_DIELECTRIC], &st.qcount[Q_EMISSIVE]};
-  uint32_t *const datas[6] = {st.qdata[q0], st.qdata[Q_CONNECT], st.qdata[Q_LAMBERTIAN], st.qdata[Q_METALLIC],
-                              st.qdata[Q_DIELECTRIC], st.qdata[Q_EMISSIVE]};
   CamBasis cb;
   if (RESPAWN) cb = cam_basis(fp.cam);
   unsigned long long finished = 0, spawned = 0;
@@ -484,7 +379,6 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
     bool have_end = false;
     if (fin) {
       slot = ext[i];
-      DPath *pp = st.path + slot;
       float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
       const float4 raw = h4[0];
       BestHit best;
@@ -495,9 +389,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
       best.inst = __float_as_uint(raw.w);
       if (best.inst == kMissInst) {
         // rad += throughput * sky
-        float4 *p4 = reinterpret_cast<float4 *>(pp);
-        float4 a = p4[0];
-        const float4 b = p4[1];
+        float4 a = path_q(st, slot, 0u);
+        const float4 b = path_q(st, slot, 1u);
         const float sky = fp.p.sky_radiance;
         a.x = a.x + b.x * sky;
         a.y = a.y + b.y * sky;
@@ -507,11 +400,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
           end_src = __float_as_uint(b.w);
           have_end = true;
         } else {
-          p4[0] = a;
+          path_q(st, slot, 0u) = a;
         }
       } else {
         hit = true;
-        if (!RAW) {
+        {
           const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
           const float4 ra = r4[0], rb = r4[1];
           v3 hp, hn;
@@ -527,23 +420,17 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
             reinterpret_cast<float4 *>(st.ray + slot)[1] = make_float4(rb.x, rb.y, tu, tv);
           }
         }
-        if (RAW) {
-          // the material kernel counts the bounce; here the slot only finds its queue
-          route = Q_LAMBERTIAN - 1u + sc.inst[best.inst].kind;
-          if (sc.inst[best.inst].kind == 0u) hit = false;  // no material: the path is dropped
-        } else {
-          // archive/extension.slang:94-101: a hit costs one bounce; out of
-          // bounces means terminate without shading
-          uint32_t *pb = reinterpret_cast<uint32_t *>(pp) + 3;
-          const uint32_t bounces = *pb - 1u;
-          *pb = bounces;
-          if (bounces == 0u) hit = false;
-          else route = Q_CONNECT;
-        }
+        // archive/extension.slang:94-101: a hit costs one bounce; out of
+        // bounces means terminate without shading
+        uint32_t &pb = path_w(st, slot, 3u);
+        const uint32_t bounces = pb - 1u;
+        pb = bounces;
+        if (bounces == 0u) hit = false;
+        else route = Q_CONNECT;
       }
       if (RESPAWN && !hit && !have_end) {
-        end_rad = reinterpret_cast<const float4 *>(pp)[0];
-        end_src = reinterpret_cast<const uint32_t *>(pp)[7];
+        end_rad = path_q(st, slot, 0u);
+        end_src = path_w(st, slot, 7u);
       }
     }
     int r = !fin ? -1 : (!hit ? 0 : (int)(route - Q_CONNECT) + 1);
@@ -558,11 +445,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
         spawn_sample(st, fp, cb, slot, si);
         spawned++;
       } else if (done) {
-        reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+        path_w(st, slot, 7u) = kNoSample;  // the slot retires
         r = -1;
       }
     }
-    block_push_n<6>(sh, counts, datas, r, slot);
+    block_push2(sh, &st.qcount[q0], st.qdata[q0], r == 0, &st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], r > 0, slot);
   }
   if (RESPAWN) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -757,10 +644,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
     float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // of a path that ends here
     uint32_t source = kNoSample;
     if (active) {
-      float4 *p4 = reinterpret_cast<float4 *>(st.path + slot);
       const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
       const float4 raw = reinterpret_cast<const float4 *>(st.hit + slot)[0];
-      float4 pa = p4[0], pb = p4[1], pr = p4[2];
+      float4 pa = path_q(st, slot, 0u), pb = path_q(st, slot, 1u), pr = path_q(st, slot, 2u);
       const float4 ra = r4[0], rb = r4[1];
       BestHit best;
       best.u = raw.x;
@@ -776,7 +662,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
         pa.y = pa.y + pb.y * sky;
         pa.z = pa.z + pb.z * sky;
         rad = pa;
-        if (!RESPAWN) p4[0] = pa;
+        if (!RESPAWN) path_q(st, slot, 0u) = pa;
       } else {
         const v3 wo = V3(ra.w, rb.x, rb.y);  // the incoming direction, not negated
         v3 hp, hn, wi;
@@ -787,9 +673,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
         shaded++;
         if (alive || !RESPAWN) {
           // (with RESPAWN a path that ends here is overwritten by its slot's next sample at once)
-          p4[0] = pa;
-          p4[1] = pb;
-          p4[2] = pr;
+          path_q(st, slot, 0u) = pa;
+          path_q(st, slot, 1u) = pb;
+          path_q(st, slot, 2u) = pr;
         }
         // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just hit is excluded
         // from the next traversal instead
@@ -808,7 +694,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
         spawned++;
         alive = true;
       } else if (done) {
-        reinterpret_cast<uint32_t *>(st.path + slot)[7] = kNoSample;  // the slot retires
+        path_w(st, slot, 7u) = kNoSample;  // the slot retires
       }
       block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
                   false, slot);
@@ -1004,15 +890,9 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
 }
 
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  const bool raw = !(fp.p.nee && fp.have_lights);  // the connect kernel needs the world-space record
   const dim3 block(kStreamBlock);
-  if (fp.respawn) {
-    if (raw) hipLaunchKernelGGL((k_extend_finish<true, true>), stream_grid(cfg, k_extend_finish<true, true>), block, 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend_finish<true, false>), stream_grid(cfg, k_extend_finish<true, false>), block, 0, cfg.stream, sc, st, fp);
-  } else {
-    if (raw) hipLaunchKernelGGL((k_extend_finish<false, true>), stream_grid(cfg, k_extend_finish<false, true>), block, 0, cfg.stream, sc, st, fp);
-    else hipLaunchKernelGGL((k_extend_finish<false, false>), stream_grid(cfg, k_extend_finish<false, false>), block, 0, cfg.stream, sc, st, fp);
-  }
+  if (fp.respawn) hipLaunchKernelGGL((k_extend_finish<true>), stream_grid(cfg, k_extend_finish<true>), block, 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_extend_finish<false>), stream_grid(cfg, k_extend_finish<false>), block, 0, cfg.stream, sc, st, fp);
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

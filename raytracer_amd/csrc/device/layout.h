@@ -131,6 +131,16 @@ struct DHit {
 };
 static_assert(sizeof(DHit) == 32, "DHit must be 32 bytes");
 
+// DPath records as three planes of float4 (see path_q in device_util.h) instead of 48-byte records.
+// Measured and not used: the queues list slots in the order paths survive, not in slot order (a render call
+// hands every slot two or three samples and then retires it, so most frames compact), and a scattered slot
+// then costs three cache lines instead of one or two: the uber shade kernel 2.29 -> 2.40 ms per launch, the
+// per-material kernels of config 2 1.65 -> 2.25 ms per frame.
+#ifndef MIRT_PATH_PLANES
+#define MIRT_PATH_PLANES 0
+#endif
+constexpr bool kPathPlanes = MIRT_PATH_PLANES != 0;
+
 struct DPath {
   float rx, ry, rz;   // radiance
   uint32_t bounces;
