@@ -194,7 +194,7 @@ def device_sources_sha():
     return h.hexdigest()[:16]
 
 
-def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
+def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths, classic=False):
     """What bounds the extend kernel, from this run's own measurements.
 
     The walk is a per-lane chain of dependent small fetches and the scene sits in L2 +
@@ -278,11 +278,11 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths):
         / elapsed / 1e9,
         "node_steps_per_s": nodes / launches / ext_s if ext_s > 0 else 0.0,
         "per_ray": per_ray,
-        "kernels": kernel_table(st, cst),
+        "kernels": kernel_table(st, cst, classic),
     }
 
 
-def kernel_table(st, cst):
+def kernel_table(st, cst, classic=False):
     """Every kernel group of the frame priced the same way: algorithmic bytes in the reference's struct sizes
     (A_extend = 112 B per ray + 64 B per node visit + 76 B per instance visit + 160 B per triangle test; A_connect =
     52 B per shadow ray + the same per visit, with the any-hit walk's own counts; A_shade = 340 B per shade event;
@@ -307,7 +307,8 @@ def kernel_table(st, cst):
             "any-hit walk of the shadow rays (stops at the first hit) and its epilogue")
     stream_ms = st.finish_ms + st.shade_ms + st.sample_ms
     stream_launches = st.finish_launches + st.shade_launches + st.sample_launches
-    names = "k_extend_finish + k_material<1..4> + k_sample" if st.finish_launches else "k_finish_shade_uber + k_sample"
+    names = ("k_extend_finish + k_material<1..4> + k_sample" if st.finish_launches else
+             "k_finish_shade_classic + k_sample" if classic else "k_finish_shade_uber + k_sample")
     row(names, stream_ms, stream_launches, 340.0 * st.shade_events + 236.0 * st.spawned_samples,
         "streaming kernels: A_shade per shade event + A_spawn per spawned sample")
     return rows
@@ -500,7 +501,8 @@ def group_mode(args):
         m0 = grp.members[0]
         cst = replay_counts(m0, [((args.warmup + k) * spp_step * n, spp_step) for k in range(args.steps)])
         assert cst.extend_counts.rays == stats[0].extend_rays, (cst.extend_counts.rays, stats[0].extend_rays)
-        roofline = extend_roofline(m0, stats[0], cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths)
+        roofline = extend_roofline(m0, stats[0], cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths,
+                                   classic=bool(info.shade_mode))
         st = stats[0]
     out = result_line(args, info, W, H, n_paths, n, elapsed, rays, samples, reduce_s, st, roofline, None,
                       per_member, f"spp split x{n}, one process (mirt_group), peer-copy reduce to member 0")
@@ -628,7 +630,8 @@ def main():
         # ---- roofline of the dominant kernel: replay the timed samples with visit counting
         cst = replay_counts(pt, [(first + args.warmup * spp_step, args.steps * spp_step)])
         assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
-        roofline = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths)
+        roofline = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths,
+                                   classic=bool(info.shade_mode))
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
