@@ -175,7 +175,7 @@ def cpu_baseline(arrays, info, W, H, src, cam, target_seconds):
             "sample": f"first {n2} of {len(src)} sample sources of the same workload, {spp} spp, {rays} rays in {dt:.2f} s"}
 
 
-DEVICE_SOURCES = ["engine.h", "kernels.hip", "kernels.h", "layout.h", "device_util.h", "rt_math.h",
+DEVICE_SOURCES = ["engine.h", "kernels.hip", "kernels.h", "layout.h", "device_util.h", "rt_math.h", "sample_stage.h",
                   "classic.hip", "api.hip"]
 
 
@@ -449,7 +449,7 @@ def secondary_line(args, local_rank):
         pt.set_camera(cam)
         steps, warmup, spp_step = 2, 1, args.spp_per_step
         elapsed, st, _ = timed_render(pt, steps, warmup, spp_step, 0)
-        cst = replay_counts(pt, [(warmup * spp_step, steps * spp_step)])
+        cst = replay_counts(pt, [((warmup + k) * spp_step, spp_step) for k in range(steps)])
         assert cst.extend_counts.rays == st.extend_rays
         rays = int(st.extend_rays + st.connect_rays)
         roof = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, geometry), n_paths)
@@ -628,7 +628,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: replay the timed samples with visit counting
-        cst = replay_counts(pt, [(first + args.warmup * spp_step, args.steps * spp_step)])
+        cst = replay_counts(pt, [(first + (args.warmup + k) * spp_step, spp_step) for k in range(args.steps)])
         assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
         roofline = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths,
                                    classic=bool(info.shade_mode))
