@@ -181,7 +181,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
   auto finish = [&](bool fin, uint32_t slot, bool occluded, float, const BestHit &) {
     if (fin) reinterpret_cast<float *>(st.shadow + slot)[7] = occluded ? 1.0f : 0.0f;
   };
-  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, cq, nullptr}, lc, fetch, finish);
+  trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, cq, nullptr, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
   if (COUNT) flush_wave_scan_counts(st.stats, S_CON_TRI_LDS, lc);
   for (int off = 32; off > 0; off >>= 1) traced += __shfl_down(traced, off);

@@ -154,7 +154,8 @@ struct WorkSource {
   uint32_t *counter;  // zeroed before the launch
   uint32_t count;     // number of queue entries
   const uint32_t *entries;  // the queue: fetch() is handed entries[i] for entry i, or i itself when this is null
-  unsigned long long *phase;  // diagnostic builds: eight cycle / iteration sums, else unused
+  unsigned long long *phase;  // diagnostic builds: sixteen cycle / iteration sums, else unused
+  uint32_t *phase_waves;      // diagnostic builds: room for sixteen words per wave of the grid (each wave's own sums), or null
 };
 
 #ifdef MIRT_PHASE_TIMING
@@ -178,6 +179,13 @@ struct WorkSource {
       atomicMax(&(ptr)[8], ph_acc[4]); /* the slowest wave */                     \
     }                                                                             \
   } while (0)
+#define MIRT_PH_FLUSH_WAVE(ptr)                                                                  \
+  do {                                                                                           \
+    if ((ptr) != nullptr && trv_lane() == 0u) {                                                  \
+      uint32_t *ph_w = (ptr) + 16u * (blockIdx.x * (kEngineBlock / 64u) + (threadIdx.x >> 6));   \
+      for (int ph_k = 0; ph_k < 16; ++ph_k) ph_w[ph_k] = (uint32_t)ph_acc[ph_k];                 \
+    }                                                                                            \
+  } while (0)
 #else
 #define MIRT_PH_DECL
 #define MIRT_PH_MARK(k)
@@ -185,6 +193,7 @@ struct WorkSource {
 #define MIRT_PH_COUNT(k)
 #define MIRT_PH_ADD(k, n)
 #define MIRT_PH_NOW() 0ull
+#define MIRT_PH_FLUSH_WAVE(ptr)
 #define MIRT_PH_FLUSH(ptr)
 #endif
 
@@ -706,6 +715,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
 #endif
   }
   MIRT_PH_FLUSH(ws.phase);
+  MIRT_PH_FLUSH_WAVE(ws.phase_waves);
 }
 
 // The record extensionMain stores for a hit (shaders/ray_extend.slang:86-89

@@ -316,6 +316,17 @@ __global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp)
 // the streaming kernel that follows; keeping the epilogue out of this kernel
 // keeps its registers and instruction footprint small.
 
+// Diagnostic builds park every wave's own phase sums in the convergence flags (unused without adaptive
+// sampling, readable with mirt_read_flags) when those have room for sixteen words per wave of the grid.
+__device__ __forceinline__ uint32_t *extend_phase_waves(const DState &st) {
+#ifdef MIRT_PHASE_TIMING
+  if (st.moments == nullptr && (size_t)st.n_sources >= (size_t)16 * gridDim.x * (kEngineBlock / 64u)) return st.flags;
+#else
+  (void)st;
+#endif
+  return nullptr;
+}
+
 template <bool COUNT>
 __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams fp) {
   const uint32_t par = fp.frame & 1u;
@@ -335,7 +346,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
       h4[0] = make_float4(best.u, best.v, __uint_as_float(best.prim), __uint_as_float(found ? best.inst : kMissInst));
     }
   };
-  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, ext, &st.stats[S_PHASE0]}, lc, fetch, finish);
+  trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, ext, &st.stats[S_PHASE0], extend_phase_waves(st)}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_EXT_TLAS, lc);
   if (COUNT) flush_wave_scan_counts(st.stats, S_EXT_TRI_LDS, lc);
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
@@ -811,7 +822,7 @@ __global__ MIRT_ENGINE_BOUNDS void k_trace(DScene sc, const DRay *rays, const fl
     reinterpret_cast<float4 *>(out)[idx] =
         make_float4(__uint_as_float(o.instance_id), __uint_as_float(o.triangle_id), o.t, __uint_as_float(o.front_face));
   };
-  trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr, nullptr}, lc, fetch, finish);
+  trace_engine<ANY, COUNT>(sc, WorkSource{work, n, nullptr, nullptr, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(counts5, 1, lc);
   if (COUNT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counts5[0], (unsigned long long)n);
 }

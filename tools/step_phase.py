@@ -32,3 +32,16 @@ if ph[9]: print(f"  per step iteration with <= 4 walking: {us(ph[10]) / ph[9]:.3
 if ph[12]: print(f"  per step iteration with 5..16 walking: {us(ph[13]) / ph[12]:.3f} us")
 rest = its - ph[9] - ph[12]
 if rest: print(f"  per step iteration with > 16 walking: {us(ph[15] - ph[10] - ph[13]) / rest:.3f} us")
+# per-wave sums of the LAST frame (parked in the convergence flags by the diagnostic build): the slowest waves
+import numpy as np
+fl = pt.read_flags()
+n_waves = 256 * 16
+if len(fl) >= 16 * n_waves:
+    w = fl[:16 * n_waves].reshape(n_waves, 16).astype(np.int64)
+    order = np.argsort(-w[:, 4])
+    tick = w[:, 4].max() / (st.extend_ms / n * 1e3)  # ticks per microsecond, taking the slowest wave for the kernel's time
+    print(f"  last frame, per wave (ticks per us ~ {tick:.0f}): busy waves {int((w[:, 5] > 0).sum())}, median wave {np.median(w[w[:, 5] > 0, 4]) / tick:.0f} us, slowest {w[order[0], 4] / tick:.0f} us")
+    for k in order[:6]:
+        r = w[k]
+        print(f"    wave {k}: {r[4] / tick:.0f} us = step loop {r[15] / tick:.0f} + service {r[14] / tick:.0f} (scans {r[7] / tick:.0f}); iterations {r[5]}, of them <=4 lanes {r[9]} ({r[10] / tick:.0f} us), 5..16 lanes {r[12]} ({r[13] / tick:.0f} us); "
+              f"service points {r[0]} (with <=4 lanes {r[11] / tick:.0f} us, 5..16 {r[2] / tick:.0f} us); lane node steps {r[1]}, walking-lane iterations {r[6]}")
