@@ -146,6 +146,10 @@ struct RayIn {
 #define MIRT_WORK_CHUNK 128u
 #endif
 constexpr uint32_t kChunk = MIRT_WORK_CHUNK;
+#ifndef MIRT_LONE_LEAF
+#define MIRT_LONE_LEAF 1
+#endif
+constexpr bool kLoneLeaf = MIRT_LONE_LEAF != 0;  // a single waiting lane's small leaf is tested without the list and the pulls
 #ifndef MIRT_PREFETCH_HK
 #define MIRT_PREFETCH_HK 1
 #endif
@@ -239,6 +243,14 @@ __device__ __forceinline__ uint32_t quad_xor1(uint32_t x) {
 }
 __device__ __forceinline__ uint32_t quad_xor2(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);
+}
+
+// the value of the mirror-image lane within each group of eight / sixteen lanes
+__device__ __forceinline__ uint32_t row_half_mirror(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_mirror(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);
 }
 
 // 16 bytes at byte offset `off` of the geometry buffer; offsets past its end read zero.
@@ -469,7 +481,74 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
       {
         const bool waits = (fl & (F_WALK | F_HOLD | F_BLAS)) == (F_WALK | F_HOLD | F_BLAS) && leaf_count != 0u;
         const unsigned long long smallmask = __ballot(waits);
-        if (smallmask != 0ull) {
+        if (kLoneLeaf && smallmask != 0ull && (smallmask & (smallmask - 1ull)) == 0ull) {
+          // ONE lane waits (a draining wave's usual case, where this sits on the ray's dependent chain): no list, no
+          // cross-lane pulls — its ray and leaf go through scalar registers, lane k tests triangle k of the leaf
+          // (fewer than kCoopLeaf of them, so one pass), the winner's key is reduced with data-parallel moves inside
+          // each row of sixteen lanes and the two rows in use meet in scalar registers.
+          const int ol = __ffsll((long long)smallmask) - 1;
+          auto rl_u = [&](uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, ol); };
+          auto rl_f = [&](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), ol)); };
+          const v3 op = V3(rl_f(cpos.x), rl_f(cpos.y), rl_f(cpos.z));
+          const v3 od = V3(rl_f(cdir.x), rl_f(cdir.y), rl_f(cdir.z));
+          const float ot = rl_f(t);
+          const uint32_t ostart = rl_u(leaf_start), ocount = rl_u(leaf_count), oskip = rl_u(excl_prim);
+          const uint32_t ofirst = rl_u(tbase) + __umul24(ostart, 48u);
+          static_assert(kCoopLeaf <= 32u, "a small leaf fits the first two rows of sixteen lanes");
+          unsigned long long key = ~0ull;
+          float ku = 0.0f, kv = 0.0f, kt = 0.0f;
+          if (lane < ocount && ostart + lane != oskip) {
+            const uint32_t toff = ofirst + __umul24(lane, 48u);
+            const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+            float t2, u, v;
+            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
+                !(t2 > ot || t2 < 0.0f)) {
+              const uint32_t p = ostart + lane;
+              key = ANY ? (unsigned long long)p
+                        : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
+              ku = u;
+              kv = v;
+              kt = t2;
+            }
+          }
+          // the smallest key of every row of sixteen lanes, in all of its lanes: lane ^ 1, lane ^ 2, then the mirror
+          // image within eight and within sixteen lanes
+          unsigned long long rkey = key;
+          for (int step = 0; step < 4; ++step) {
+            const uint32_t klo = (uint32_t)rkey, khi = (uint32_t)(rkey >> 32);
+            uint32_t olo, ohi;
+            if (step == 0) { olo = quad_xor1(klo); ohi = quad_xor1(khi); }
+            else if (step == 1) { olo = quad_xor2(klo); ohi = quad_xor2(khi); }
+            else if (step == 2) { olo = row_half_mirror(klo); ohi = row_half_mirror(khi); }
+            else { olo = row_mirror(klo); ohi = row_mirror(khi); }
+            const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+            rkey = other < rkey ? other : rkey;
+          }
+          const unsigned long long r0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rkey >> 32), 0) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, 0);
+          const unsigned long long r1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rkey >> 32), 16) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rkey, 16);
+          const unsigned long long wkey = r0 < r1 ? r0 : r1;
+          const bool won = wkey != ~0ull;
+          float wu = 0.0f, wv = 0.0f, wt = 0.0f;
+          if (won) {
+            const int winner = __ffsll((long long)__ballot(key == wkey)) - 1;
+            wu = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ku), winner));
+            wv = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(kv), winner));
+            wt = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(kt), winner));
+          }
+          if ((int)lane == ol) {
+            const uint32_t wp = ANY ? (uint32_t)wkey : ~(uint32_t)wkey;
+            if (COUNT) {
+              const uint32_t tested = (ANY && won) ? (wp - leaf_start + 1u) : leaf_count;
+              const bool skipped = excl_prim >= leaf_start && excl_prim < leaf_start + tested;
+              lc.triangles += tested - (skipped ? 1u : 0u);
+            }
+            if (won) accept(wt, wu, wv, wp);
+            leaf_count = 0u;
+            if ((fl & F_WRAP) == 0u) fl &= ~F_HOLD;
+          }
+        } else if (smallmask != 0ull) {
           const uint32_t n_wait = (uint32_t)__popcll(smallmask);
           const uint32_t rank = trv_rank(smallmask);  // among the waiting lanes, in lane order
           if (waits) own[rank] = lane;
