@@ -275,10 +275,12 @@ typedef struct MirtStats {
    * 36 B per triangle).  The remaining tests fetched one 48-B record each. */
   uint64_t extend_tri_wave_lds, extend_tri_wave_mem;
   uint64_t connect_tri_wave_lds, connect_tri_wave_mem;
-  /* adds that found a 32-bit radiance sum at its limit: the sum stays at
-   * 2^32 - 1 instead of wrapping as the reference's InterlockedAdd does
-   * (shaders/sample.slang:45-47).  Non-zero means the image is clipped there:
-   * render fewer samples per accumulator or lower fixed_point_scale. */
+  /* radiance sums (channels) that stand at the 32-bit limit when the statistics
+   * are read: a sum ends on 2^32 - 1 instead of wrapping as the reference's
+   * InterlockedAdd does (shaders/sample.slang:45-47) — inside, the sums are
+   * 64-bit and are clamped wherever they are handed out.  Non-zero means the
+   * image is clipped there: render fewer samples per accumulator or lower
+   * fixed_point_scale.  Not cleared by mirt_stats_reset: it describes the sums. */
   uint64_t overflowed_sums;
   /* diagnostic builds only (-DMIRT_PHASE_TIMING), summed over the waves of the
    * extend kernel (times in ticks of the 100 MHz constant clock): [0] service
@@ -376,8 +378,11 @@ int mirt_synchronize(mirt_ctx *ctx);
  * the means and return width*height packed pixels (R | G<<8 | B<<16). */
 int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels);
 
-/* Raw accumulators: sum4[4*n] (x,y,z fixed-point, w unused) and count[n],
- * indexed by sample source. */
+/* Raw accumulators in the reference's format (shaders/pathtracer.slang:30):
+ * sum4[4*n] (x,y,z fixed-point, w unused) and count[n], indexed by sample
+ * source.  Inside, each sum is a 64-bit word (it cannot wrap); what is handed
+ * out here, to mirt_copy_accum_to_device and to the resolve is
+ * min(sum, 2^32 - 1). */
 int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count,
                     size_t n_sources);
 
@@ -404,8 +409,11 @@ int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources);
 int mirt_read_moments(mirt_ctx *ctx, uint64_t *moments, size_t n_sources);
 int mirt_write_moments(mirt_ctx *ctx, const uint64_t *moments, size_t n_sources);
 
-/* Copy the accumulators into caller-owned DEVICE buffers (for an RCCL
- * reduction driven by the caller) and load reduced values back. */
+/* Copy the accumulators (sum4 as mirt_read_accum hands it out: 16 bytes per
+ * source, 16-byte aligned) into caller-owned DEVICE buffers (for an RCCL
+ * reduction driven by the caller) and load reduced values back.  A caller that
+ * adds sums across ranks widens them, adds, and clamps to 2^32 - 1 before
+ * loading, so that the total ends where one GPU's would. */
 int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count,
                               size_t n_sources);
 int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4,
@@ -528,7 +536,7 @@ int mirt_group_reset_accum(mirt_group *grp);
  * them (the first spp % n members one more), all members at once. */
 int mirt_group_render_spp(mirt_group *grp, uint32_t spp);
 /* Member 0 += members 1..n-1, whose accumulators are then cleared: the
- * saturating radiance sums, the counts and, with adaptive sampling, the integer
+ * radiance sums (64-bit inside: they cannot wrap), the counts and, with adaptive sampling, the integer
  * moments. */
 int mirt_group_reduce(mirt_group *grp);
 /* mirt_adapt_update for the group: reduces (as above), flags the converged

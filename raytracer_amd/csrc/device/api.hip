@@ -100,6 +100,7 @@ struct mirt_ctx {
   bool rng_seeded = false;   // per-slot streams: mirt_state_set_rng has been called
   uint32_t stamp = 0;        // per-slot streams: last value written to DState::slot_stamp
   uint32_t *d_active = nullptr;  // the list DState::active points at (owned by state_allocs)
+  uint32_t *d_export4 = nullptr; // staging for mirt_read_accum: the sums as 32-bit words (owned by state_allocs)
 
   // diagnostics
   bool counting = false;
@@ -1067,10 +1068,11 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if ((rc = dev_alloc(ctx, own, &dsrc, n_sources)) != MIRT_OK) return rc;
   HIP_TRY(ctx, copy_sync(ctx->stream, dsrc, sources, (size_t)n_sources * sizeof(MirtSampleSource), hipMemcpyHostToDevice));
   st.sources = dsrc;
-  if ((rc = dev_alloc(ctx, own, &st.sum4, (size_t)4 * n_sources)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &st.sum3, (size_t)kSumStride * n_sources)) != MIRT_OK) return rc;
+  if ((rc = dev_alloc(ctx, own, &ctx->d_export4, (size_t)4 * n_sources)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.count, n_sources)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.output, (size_t)width * height)) != MIRT_OK) return rc;
-  HIP_TRY(ctx, hipMemsetAsync(st.sum4, 0, (size_t)16 * n_sources, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(st.sum3, 0, (size_t)8 * kSumStride * n_sources, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(st.count, 0, (size_t)4 * n_sources, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(st.output, 0, (size_t)4 * width * height, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(st.stats, 0, S_COUNT * sizeof(unsigned long long), ctx->stream));
@@ -1232,7 +1234,7 @@ int mirt_reset_accum(mirt_ctx *ctx) {
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   // sampleCleanup (shaders/sample.slang:123-145) for every source, including
   // the tail its integer work split leaves out.  Counts restart at 0, not 1.
-  HIP_TRY(ctx, hipMemsetAsync(ctx->st.sum4, 0, (size_t)16 * ctx->st.n_sources, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->st.sum3, 0, (size_t)8 * kSumStride * ctx->st.n_sources, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(ctx->st.count, 0, (size_t)4 * ctx->st.n_sources, ctx->stream));
   // ... and every source takes samples again (sample.slang:137 clears the flags)
   HIP_TRY(ctx, hipMemsetAsync(ctx->st.flags, 0, (size_t)4 * ctx->st.n_sources, ctx->stream));
@@ -1331,7 +1333,12 @@ int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count, size_t n_sou
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_accum: n_sources mismatch");
-  if (sum4) HIP_TRY(ctx, hipMemcpyAsync(sum4, ctx->st.sum4, n_sources * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (sum4) {
+    // the 64-bit sums the kernels keep, as the reference's 32-bit words (clamped to 2^32 - 1)
+    launch_export_sums(launch_cfg(ctx), ctx->st, ctx->d_export4);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(sum4, ctx->d_export4, n_sources * 16, hipMemcpyDeviceToHost, ctx->stream));
+  }
   if (count) HIP_TRY(ctx, hipMemcpyAsync(count, ctx->st.count, n_sources * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev_collect(ctx);
@@ -1342,7 +1349,10 @@ int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count, si
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "copy_accum: n_sources mismatch");
-  if (dev_sum4) HIP_TRY(ctx, hipMemcpyAsync(dev_sum4, ctx->st.sum4, n_sources * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  if (dev_sum4) {
+    launch_export_sums(launch_cfg(ctx), ctx->st, static_cast<uint32_t *>(dev_sum4));
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(dev_count, ctx->st.count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
@@ -1352,7 +1362,10 @@ int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4, const void 
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "load_accum: n_sources mismatch");
-  if (dev_sum4) HIP_TRY(ctx, hipMemcpyAsync(ctx->st.sum4, dev_sum4, n_sources * 16, hipMemcpyDeviceToDevice, ctx->stream));
+  if (dev_sum4) {
+    launch_import_sums(launch_cfg(ctx), ctx->st, static_cast<const uint32_t *>(dev_sum4));
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(ctx->st.count, dev_count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
@@ -1509,6 +1522,10 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
   if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "stats: null pointer");
   memset(out, 0, sizeof(*out));
   if (ctx->have_state) {
+    // the overflow statistic is a property of the sums as they stand: counted now
+    HIP_TRY(ctx, hipMemsetAsync(&ctx->st.stats[S_OVERFLOW], 0, sizeof(unsigned long long), ctx->stream));
+    launch_count_saturated(launch_cfg(ctx), ctx->st);
+    HIP_TRY(ctx, hipGetLastError());
     int rc = fetch_counters(ctx);
     if (rc != MIRT_OK) return rc;
     const unsigned long long *s = ctx->h_stats;
@@ -1623,7 +1640,8 @@ struct mirt_group {
   std::string error;
   uint32_t next_sample = 0;  // the group's sample-number cursor
   // staging for the reduction, on member 0's device: one copy of the accumulators per other member
-  std::vector<uint32_t *> tmp_sum4, tmp_count;
+  std::vector<unsigned long long *> tmp_sum3;
+  std::vector<uint32_t *> tmp_count;
   std::vector<unsigned long long *> tmp_moments;  // adaptive states only
   std::vector<hipEvent_t> copied;  // member i's copies into its staging have been issued up to here
   size_t tmp_sources = 0;
@@ -1652,10 +1670,10 @@ int for_members(mirt_group *g, const char *what, F call) {
 void group_free_staging(mirt_group *g) {
   if (g->members.empty()) return;
   if (hipSetDevice(g->members[0]->device) != hipSuccess) return;
-  for (uint32_t *p : g->tmp_sum4) (void)hipFree(p);
+  for (unsigned long long *p : g->tmp_sum3) (void)hipFree(p);
   for (uint32_t *p : g->tmp_count) (void)hipFree(p);
   for (unsigned long long *p : g->tmp_moments) (void)hipFree(p);
-  g->tmp_sum4.clear();
+  g->tmp_sum3.clear();
   g->tmp_count.clear();
   g->tmp_moments.clear();
   g->tmp_sources = 0;
@@ -1876,13 +1894,14 @@ int mirt_group_reduce(mirt_group *g) {
     if (_e != hipSuccess) return gfail(g, MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
   GROUP_TRY(hipSetDevice(root->device));
-  if (g->tmp_sources != ns || g->tmp_sum4.size() != n - 1 || (with_moments && g->tmp_moments.size() != n - 1)) {
+  if (g->tmp_sources != ns || g->tmp_sum3.size() != n - 1 || (with_moments && g->tmp_moments.size() != n - 1)) {
     group_free_staging(g);
     GROUP_TRY(hipSetDevice(root->device));
     for (size_t i = 1; i < n; ++i) {
-      uint32_t *a = nullptr, *b = nullptr;
-      GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&a), ns * 16));
-      g->tmp_sum4.push_back(a);
+      unsigned long long *a = nullptr;
+      uint32_t *b = nullptr;
+      GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&a), ns * 8 * kSumStride));
+      g->tmp_sum3.push_back(a);
       GROUP_TRY(hipMalloc(reinterpret_cast<void **>(&b), ns * 4));
       g->tmp_count.push_back(b);
       if (with_moments) {
@@ -1905,19 +1924,19 @@ int mirt_group_reduce(mirt_group *g) {
   for (size_t i = 1; i < n; ++i) {
     mirt_ctx *c = g->members[i];
     GROUP_TRY(hipSetDevice(c->device));
-    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum4[i - 1], root->device, c->st.sum4, c->device, ns * 16, c->stream));
+    GROUP_TRY(hipMemcpyPeerAsync(g->tmp_sum3[i - 1], root->device, c->st.sum3, c->device, ns * 8 * kSumStride, c->stream));
     GROUP_TRY(hipMemcpyPeerAsync(g->tmp_count[i - 1], root->device, c->st.count, c->device, ns * 4, c->stream));
     if (with_moments)
       GROUP_TRY(hipMemcpyPeerAsync(g->tmp_moments[i - 1], root->device, c->st.moments, c->device, ns * 16, c->stream));
     GROUP_TRY(hipEventRecord(g->copied[i - 1], c->stream));
-    GROUP_TRY(hipMemsetAsync(c->st.sum4, 0, ns * 16, c->stream));
+    GROUP_TRY(hipMemsetAsync(c->st.sum3, 0, ns * 8 * kSumStride, c->stream));
     GROUP_TRY(hipMemsetAsync(c->st.count, 0, ns * 4, c->stream));
     if (with_moments) GROUP_TRY(hipMemsetAsync(c->st.moments, 0, ns * 16, c->stream));
   }
   GROUP_TRY(hipSetDevice(root->device));
   for (size_t i = 1; i < n; ++i) {
     GROUP_TRY(hipStreamWaitEvent(root->stream, g->copied[i - 1], 0));
-    launch_accum_add(launch_cfg(root), root->st.sum4, g->tmp_sum4[i - 1], ns * 4, true);
+    launch_accum_add64(launch_cfg(root), root->st.sum3, g->tmp_sum3[i - 1], ns * kSumStride);  // 64-bit: clamped when handed out
     launch_accum_add(launch_cfg(root), root->st.count, g->tmp_count[i - 1], ns, false);
     if (with_moments) launch_accum_add64(launch_cfg(root), root->st.moments, g->tmp_moments[i - 1], ns * 2);
   }

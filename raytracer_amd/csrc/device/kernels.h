@@ -31,10 +31,17 @@ enum StatId {
   S_EXTEND_RAYS = 0, S_CONNECT_RAYS, S_SHADE_EVENTS, S_SPAWNED, S_FINISHED,
   S_EXT_TLAS, S_EXT_INST, S_EXT_BLAS, S_EXT_TRI, S_CON_TLAS, S_CON_INST, S_CON_BLAS, S_CON_TRI,
   S_EXT_TRI_LDS, S_EXT_TRI_MEM, S_CON_TRI_LDS, S_CON_TRI_MEM,  // whole-wave scans, by where they read their triangles
-  S_OVERFLOW,  // samples whose add would have wrapped a 32-bit radiance sum (the sum saturates instead)
+  S_OVERFLOW,  // channel sums at or beyond 2^32 - 1 (handed out as 2^32 - 1), counted when the statistics are read
   S_PHASE0,  // sixteen words written only by diagnostic builds (-DMIRT_PHASE_TIMING)
   S_COUNT = S_PHASE0 + 16
 };
+
+// words per source in DState::sum3: r, g, b.  MIRT_SUM_STRIDE=4 pads them so that one source's words share a
+// 32-byte sector; measured slower (the streaming kernels +2 to +3 % in time): the footprint is what costs.
+#ifndef MIRT_SUM_STRIDE
+#define MIRT_SUM_STRIDE 3
+#endif
+constexpr uint32_t kSumStride = MIRT_SUM_STRIDE;
 
 struct DState {
   DRay *ray;            // [slots]
@@ -46,7 +53,10 @@ struct DState {
   unsigned long long *stats;         // [S_COUNT]
   unsigned long long *sample_index;  // next sample to hand out in this render call
   const MirtSampleSource *sources;   // [n_sources]
-  uint32_t *sum4;       // [4 * n_sources]
+  // radiance sums, three 64-bit words per source (r, g, b in fixed point).  The reference's 32-bit words
+  // (shaders/pathtracer.slang:30) are what every boundary hands out — clamped to 2^32 - 1 there
+  // (launch_export_sums) — but inside, a sum that cannot wrap is added to with atomics that return nothing.
+  unsigned long long *sum3;  // [kSumStride * n_sources]
   uint32_t *count;      // [n_sources]
   uint32_t *output;     // [width * height]
   uint32_t slots, n_sources, width, height;
@@ -129,6 +139,12 @@ void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &
 // dst[i] += src[i] for n words (the integer accumulators of another context)
 void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, size_t n, bool saturate);
 void launch_accum_add64(const LaunchCfg &cfg, unsigned long long *dst, const unsigned long long *src, size_t n);
+// the sums in the reference's format: dst4[4 * i + c] = min(sum3[3 * i + c], 2^32 - 1), dst4[4 * i + 3] = 0
+void launch_export_sums(const LaunchCfg &cfg, const DState &st, uint32_t *dst4);
+// ... and back: sum3[3 * i + c] = src4[4 * i + c]
+void launch_import_sums(const LaunchCfg &cfg, const DState &st, const uint32_t *src4);
+// stats[S_OVERFLOW] += the number of channel sums at or beyond 2^32 - 1
+void launch_count_saturated(const LaunchCfg &cfg, const DState &st);
 void launch_init_slots(const LaunchCfg &cfg, const DState &st);
 // frame 0 of a render call: the first min(slots, sample_limit) samples spawned into slots 0.. (no terminate queue pass)
 void launch_spawn_first(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp);

@@ -761,6 +761,34 @@ __global__ __launch_bounds__(256) void k_accum_add64(unsigned long long *__restr
   if (i < n) dst[i] += src[i];
 }
 
+// The sums in the reference's format (shaders/pathtracer.slang:30: three fixed-point words and an unused
+// one per source), clamped to 2^32 - 1, and back.
+__global__ __launch_bounds__(256) void k_export_sums(DState st, uint32_t *__restrict__ dst4) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= st.n_sources) return;
+  uint4 o;
+  const unsigned long long a = st.sum3[kSumStride * (size_t)i], b = st.sum3[kSumStride * (size_t)i + 1], c = st.sum3[kSumStride * (size_t)i + 2];
+  o.x = a > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)a;
+  o.y = b > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b;
+  o.z = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+  o.w = 0u;
+  reinterpret_cast<uint4 *>(dst4)[i] = o;
+}
+__global__ __launch_bounds__(256) void k_import_sums(DState st, const uint32_t *__restrict__ src4) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= st.n_sources) return;
+  const uint4 v = reinterpret_cast<const uint4 *>(src4)[i];
+  st.sum3[kSumStride * (size_t)i] = v.x;
+  st.sum3[kSumStride * (size_t)i + 1] = v.y;
+  st.sum3[kSumStride * (size_t)i + 2] = v.z;
+}
+__global__ __launch_bounds__(256) void k_count_saturated(DState st) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  const bool over = i < kSumStride * (size_t)st.n_sources && st.sum3[i] >= 0xFFFFFFFFull;  // reads as 2^32 - 1: at the limit
+  const unsigned long long m = __ballot(over);
+  if (lane_id() == 0u && m != 0ull) atomicAdd(&st.stats[S_OVERFLOW], (unsigned long long)__popcll(m));
+}
+
 // --------------------------------------------------------------- resolve
 
 __device__ __forceinline__ float saturate(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
@@ -777,7 +805,11 @@ __global__ __launch_bounds__(256) void k_resolve(DState st, DFrameParams fp) {
   const uint32_t cnt = st.count[i];
   const float denom = fp.p.fixed_point_scale * (float)cnt;
   float rad[3], v[3], c[3], o[3];
-  for (int k = 0; k < 3; ++k) rad[k] = ((float)st.sum4[4 * (size_t)i + k] / denom) * fp.p.exposure;
+  for (int k = 0; k < 3; ++k) {
+    const unsigned long long wide = st.sum3[kSumStride * (size_t)i + k];
+    const uint32_t sum = wide > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)wide;  // the 32-bit word the reference keeps
+    rad[k] = ((float)sum / denom) * fp.p.exposure;
+  }
   const float m1[3][3] = {{0.59719f, 0.35458f, 0.04823f}, {0.07600f, 0.90834f, 0.01566f}, {0.02840f, 0.13383f, 0.83770f}};
   const float m2[3][3] = {{1.60475f, -0.53108f, -0.07367f}, {-0.10208f, 1.10813f, -0.00605f}, {-0.00327f, -0.07276f, 1.07602f}};
   for (int k = 0; k < 3; ++k) v[k] = m1[k][0] * rad[0] + m1[k][1] * rad[1] + m1[k][2] * rad[2];
@@ -922,6 +954,17 @@ void launch_accum_add(const LaunchCfg &cfg, uint32_t *dst, const uint32_t *src, 
 void launch_accum_add64(const LaunchCfg &cfg, unsigned long long *dst, const unsigned long long *src, size_t n) {
   if (n == 0) return;
   hipLaunchKernelGGL(k_accum_add64, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, cfg.stream, dst, src, n);
+}
+
+void launch_export_sums(const LaunchCfg &cfg, const DState &st, uint32_t *dst4) {
+  hipLaunchKernelGGL(k_export_sums, dim3((st.n_sources + 255u) / 256u), dim3(256), 0, cfg.stream, st, dst4);
+}
+void launch_import_sums(const LaunchCfg &cfg, const DState &st, const uint32_t *src4) {
+  hipLaunchKernelGGL(k_import_sums, dim3((st.n_sources + 255u) / 256u), dim3(256), 0, cfg.stream, st, src4);
+}
+void launch_count_saturated(const LaunchCfg &cfg, const DState &st) {
+  const size_t n = kSumStride * (size_t)st.n_sources;
+  hipLaunchKernelGGL(k_count_saturated, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, cfg.stream, st);
 }
 
 void launch_resolve(const LaunchCfg &cfg, const DState &st, const DFrameParams &fp) {

@@ -19,34 +19,25 @@ __device__ __forceinline__ uint32_t to_fixed(float rad, float scale) {
   return (uint32_t)x;
 }
 
-// One channel of a sum.  The reference's InterlockedAdd wraps; here a sum that
-// would pass 2^32 - 1 ends on 2^32 - 1 whatever the order of the adds: an add that
-// wraps is followed by an atomic max with 2^32 - 1, and so is every positive
-// add that comes after it.  Returns true when that happened.
-__device__ __forceinline__ bool add_saturating(uint32_t *p, uint32_t v) {
-  if (v == 0u) return false;
-  const uint32_t old = atomicAdd(p, v);
-  if (old + v >= old) return false;
-  atomicMax(p, 0xFFFFFFFFu);
-  return true;
-}
-
-// accumulateSample's sums (shaders/sample.slang:38-47) for one finished sample
+// accumulateSample's sums (shaders/sample.slang:38-47) for one finished sample.  The reference's InterlockedAdd
+// on 32-bit words wraps; here the sums are 64-bit inside (they cannot wrap: 2^32 adds of the largest value fit)
+// and are clamped to 2^32 - 1 wherever they are handed out, so a sum that would pass 2^32 - 1 ends on 2^32 - 1
+// whatever the order of the adds — and the adds need not return the old value, which is what they cost: a
+// returning atomic's data comes back through the L1's miss queue like a load's.
 __device__ __forceinline__ void accumulate_sample(const DState &st, const DFrameParams &fp, uint32_t source, float4 rad) {
   atomicAdd(&st.count[source], 1u);
-  uint32_t *sum = &st.sum4[4 * (size_t)source];
-  const bool o0 = add_saturating(sum + 0, to_fixed(rad.x, fp.p.fixed_point_scale));
-  const bool o1 = add_saturating(sum + 1, to_fixed(rad.y, fp.p.fixed_point_scale));
-  const bool o2 = add_saturating(sum + 2, to_fixed(rad.z, fp.p.fixed_point_scale));
-  if (o0 || o1 || o2) atomicAdd(&st.stats[S_OVERFLOW], (unsigned long long)((o0 ? 1 : 0) + (o1 ? 1 : 0) + (o2 ? 1 : 0)));
+  unsigned long long *sum = &st.sum3[kSumStride * (size_t)source];
+  const uint32_t v0 = to_fixed(rad.x, fp.p.fixed_point_scale), v1 = to_fixed(rad.y, fp.p.fixed_point_scale),
+                 v2 = to_fixed(rad.z, fp.p.fixed_point_scale);
+  if (v0 != 0u) atomicAdd(sum + 0, (unsigned long long)v0);
+  if (v1 != 0u) atomicAdd(sum + 1, (unsigned long long)v1);
+  if (v2 != 0u) atomicAdd(sum + 2, (unsigned long long)v2);
   if (st.moments != nullptr) {
     // adaptive sampling: first and second moment of the sample's value y = r + g + b in fixed point,
     // clamped to 24 bits so that 2^16 squares fit 64 bits — integers, so that sums from several
     // GPUs add exactly (the reference declares a float4 sample_std for this, shaders/pathtracer.slang:31,
     // and never writes it)
-    unsigned long long y = (unsigned long long)to_fixed(rad.x, fp.p.fixed_point_scale) +
-                           (unsigned long long)to_fixed(rad.y, fp.p.fixed_point_scale) +
-                           (unsigned long long)to_fixed(rad.z, fp.p.fixed_point_scale);
+    unsigned long long y = (unsigned long long)v0 + (unsigned long long)v1 + (unsigned long long)v2;
     if (y > 0xFFFFFFull) y = 0xFFFFFFull;
     atomicAdd(&st.moments[2 * (size_t)source], y);
     atomicAdd(&st.moments[2 * (size_t)source + 1], y * y);
