@@ -1000,3 +1000,21 @@ def test_radiance_sums_saturate_and_report_instead_of_wrapping(pt, config_scenes
         grp.reduce()
         g4, gcnt = grp.read_accum()
     assert np.array_equal(g4, w4) and np.array_equal(gcnt, wcnt)
+    # the sums as a caller's collective sees them: copied to device buffers clamped, loaded back, added to again —
+    # what stood at the limit stays there, the statistic still reports it, and everything ends on the bits of one
+    # uninterrupted render of as many samples (per-sample streams: sample numbers 0..23 then 24..35)
+    import torch
+    d4 = torch.zeros(4 * len(src), dtype=torch.int32, device="cuda:0")
+    dc = torch.zeros(len(src), dtype=torch.int32, device="cuda:0")
+    pt.copy_accum_to_device(d4.data_ptr(), dc.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d4.cpu().numpy().view("<u4"), s4) and np.array_equal(dc.cpu().numpy().view("<u4"), cnt)
+    pt.reset_accum()
+    pt.load_accum_from_device(d4.data_ptr(), dc.data_ptr())
+    assert pt.stats().overflowed_sums > 0
+    pt.set_sample_range(24)
+    pt.render_spp(12)
+    t4, tcnt = pt.read_accum()
+    x4, xcnt, _ = po.Scene(hot).render(cam, src, W, H, po.default_params(max_bounces=4, seed=3), 0, 36)
+    assert np.array_equal(t4, x4) and np.array_equal(tcnt, xcnt)
+    assert (t4 == 0xFFFFFFFF).sum() >= (s4 == 0xFFFFFFFF).sum()
