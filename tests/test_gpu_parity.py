@@ -7,6 +7,7 @@ fixed-point radiance sums, sample counts and tone-mapped pixels are all compared
 BIT-EXACT (tolerance 0): the kernels and the oracle share one arithmetic
 contract (f32, no implicit contraction, correctly rounded / and sqrt).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -956,6 +957,19 @@ def test_group_on_two_distinct_devices_when_the_box_has_them(config_scenes):
     assert np.array_equal(s5, o4) and np.array_equal(c5, oc)
 
 
+def _loaded_hip_runtime():
+    """The HIP runtime the device library has already loaded into this process (a second copy, such as the one
+    torch ships, finds no device once the first holds it)."""
+    with open("/proc/self/maps") as f:
+        paths = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+    assert paths, "the device library has not loaded a HIP runtime"
+    hip = C.CDLL(sorted(paths)[0])
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    return hip
+
+
 def test_radiance_sums_saturate_and_report_instead_of_wrapping(pt, config_scenes):
     # configuration 5's scene at its own fixed-point scale, 64 samples per pixel on a 256 x 256
     # image: no sum comes near 32 bits, and the statistic says so
@@ -1003,14 +1017,17 @@ def test_radiance_sums_saturate_and_report_instead_of_wrapping(pt, config_scenes
     # the sums as a caller's collective sees them: copied to device buffers clamped, loaded back, added to again —
     # what stood at the limit stays there, the statistic still reports it, and everything ends on the bits of one
     # uninterrupted render of as many samples (per-sample streams: sample numbers 0..23 then 24..35)
-    import torch
-    d4 = torch.zeros(4 * len(src), dtype=torch.int32, device="cuda:0")
-    dc = torch.zeros(len(src), dtype=torch.int32, device="cuda:0")
-    pt.copy_accum_to_device(d4.data_ptr(), dc.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(d4.cpu().numpy().view("<u4"), s4) and np.array_equal(dc.cpu().numpy().view("<u4"), cnt)
+    hip = _loaded_hip_runtime()
+    d4, dc = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d4), 16 * len(src)) == 0 and hip.hipMalloc(C.byref(dc), 4 * len(src)) == 0
+    pt.copy_accum_to_device(d4.value, dc.value)
+    assert hip.hipDeviceSynchronize() == 0
+    b4, bc = np.zeros(4 * len(src), "<u4"), np.zeros(len(src), "<u4")
+    assert hip.hipMemcpy(C.c_void_p(b4.ctypes.data), d4, b4.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+    assert hip.hipMemcpy(C.c_void_p(bc.ctypes.data), dc, bc.nbytes, 2) == 0
+    assert np.array_equal(b4, s4) and np.array_equal(bc, cnt)
     pt.reset_accum()
-    pt.load_accum_from_device(d4.data_ptr(), dc.data_ptr())
+    pt.load_accum_from_device(d4.value, dc.value)
     assert pt.stats().overflowed_sums > 0
     pt.set_sample_range(24)
     pt.render_spp(12)
@@ -1018,3 +1035,4 @@ def test_radiance_sums_saturate_and_report_instead_of_wrapping(pt, config_scenes
     x4, xcnt, _ = po.Scene(hot).render(cam, src, W, H, po.default_params(max_bounces=4, seed=3), 0, 36)
     assert np.array_equal(t4, x4) and np.array_equal(tcnt, xcnt)
     assert (t4 == 0xFFFFFFFF).sum() >= (s4 == 0xFFFFFFFF).sum()
+    assert hip.hipFree(d4) == 0 and hip.hipFree(dc) == 0
