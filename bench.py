@@ -68,6 +68,9 @@ def parse():
                     help="step mode: per-sample keyed streams (the default everywhere) or the reference's persistent "
                          "stream per path slot (src/pathtracer_state.rs:98-110), which the Rust shim selects; the sample "
                          "stage then pairs slots with sample numbers in ascending slot order")
+    ap.add_argument("--stage-kernels", action="store_true",
+                    help="per-material shading with light sampling (config 5): a routing pass and one kernel per "
+                         "material behind the connect kernel (MirtParams.stage_kernels) instead of one kernel")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -303,11 +306,11 @@ def kernel_table(st, cst, classic=False):
     row("k_extend", st.extend_ms, st.extend_launches, cst.extend_counts.algorithmic_bytes(112),
         "closest-hit walk; reference-layout units, not memory traffic")
     if st.connect_launches:
-        row("k_connect + k_connect_finish", st.connect_ms, st.connect_launches, cst.connect_counts.algorithmic_bytes(52),
-            "any-hit walk of the shadow rays (stops at the first hit) and its epilogue")
+        row("k_connect", st.connect_ms, st.connect_launches, cst.connect_counts.algorithmic_bytes(52),
+            "any-hit walk of the shadow rays (stops at the first hit)")
     stream_ms = st.finish_ms + st.shade_ms + st.sample_ms
     stream_launches = st.finish_launches + st.shade_launches + st.sample_launches
-    names = ("k_extend_finish + k_material<1..4> + k_sample" if st.finish_launches else
+    names = ("k_extend_finish + k_connect_shade (or k_connect_finish + k_material<1..4>) + k_sample" if st.finish_launches else
              "k_finish_shade_classic + k_sample" if classic else "k_finish_shade_uber + k_sample")
     row(names, stream_ms, stream_launches, 340.0 * st.shade_events + 236.0 * st.spawned_samples,
         "streaming kernels: A_shade per shade event + A_spawn per spawned sample")
@@ -393,7 +396,7 @@ def build_workload(args, geometry):
     src = host.make_sample_sources(W, H, info.seed, shuffle=2)
     cam = host.default_camera(W, H)
     params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
-                                       nee=info.nee)
+                                       nee=info.nee, stage_kernels=1 if args.stage_kernels else 0)
     return arrays, info, W, H, src, cam, params
 
 

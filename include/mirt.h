@@ -226,7 +226,10 @@ typedef struct MirtParams {
   uint32_t nee;           /* classic mode: 1 = trace connect (shadow) rays */
   uint32_t adaptive;      /* 1 = keep per-source second moments (the reference's unused sample_std,
                              shaders/pathtracer.slang:31) so that mirt_adapt_update can flag sources */
-  uint32_t reserved;      /* 0 */
+  uint32_t stage_kernels; /* classic mode with nee: 1 = behind the connect kernel, a routing pass and one
+                             kernel per material, each popping its own queue, as the archive frame dispatches
+                             its material phases (src/app.rs:402-410); 0 = the hit material's shade event in
+                             one kernel over the connect queue.  Same results either way. */
 } MirtParams;
 
 /* --------------------------------------------------------------- ray-set API */

@@ -61,7 +61,7 @@ def default_params(**kw):
     """The reference's literals (MirtParams); keyword arguments override."""
     p = ffi.Params(max_bounces=128, sky_radiance=10.0, fixed_point_scale=1000.0,
                    exposure=float(np.exp2(np.float32(-2.5))), shade_mode=0, rng_mode=0, seed=0x5EED0000, nee=0,
-                   adaptive=0, reserved=0)
+                   adaptive=0, stage_kernels=0)
     for k, v in kw.items():
         setattr(p, k, v)
     return p

@@ -495,12 +495,12 @@ int seed_slots(mirt_ctx *c) {
   return MIRT_OK;
 }
 
-// `respawn`: the kernel that runs the extend epilogue (the shade kernel with
-// uber shading, k_extend_finish with per-material shading) accumulates and
-// respawns the paths that end in it.  With uber shading the sample kernel then
-// finds an empty terminate queue after the first frame and only clears the idle
-// queue counters; with per-material shading it is left with the paths that end
-// in a material kernel.
+// `respawn`: the kernels in which paths end (the shade kernel with uber
+// shading; k_extend_finish and the material kernel with per-material shading)
+// accumulate them and respawn their slots at once.  The sample kernel then finds
+// an empty terminate queue after the first frame and only clears the idle queue
+// counters — except with MirtParams.stage_kernels, where it is left with the
+// paths that end in one of the four material kernels.
 void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_sample, bool respawn) {
   const LaunchCfg cfg = launch_cfg(c);
   const bool per_slot = c->params.rng_mode == MIRT_RNG_PER_SLOT;
@@ -517,10 +517,12 @@ void run_frame(mirt_ctx *c, unsigned long long sample_limit, uint32_t first_samp
     // no light sampling: nothing sits between the extend epilogue and the material, one launch does both
     timed_launch(c, K_SHADE, [&] { launch_finish_shade_classic(cfg, c->sc, c->st, fp); });
   } else if (c->params.shade_mode == MIRT_SHADE_CLASSIC) {
-    // light sampling: epilogue with world-space hit records, the connect stage, then one kernel per material
+    // light sampling: the epilogue with world-space hit records and the light sample, the shadow rays, then
+    // the materials — in one kernel, or routed to one kernel per material
     timed_launch(c, K_FINISH, [&] { launch_extend_finish(cfg, c->sc, c->st, fp); });
     timed_launch(c, K_CONNECT, [&] { launch_connect(cfg, c->sc, c->st, fp); });
-    timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
+    if (c->params.stage_kernels != 0u) timed_launch(c, K_SHADE, [&] { launch_shade_classic(cfg, c->sc, c->st, fp); });
+    else timed_launch(c, K_SHADE, [&] { launch_connect_shade(cfg, c->sc, c->st, fp); });
   } else {
     // uber shading: the extend epilogue and the shade kernel are one launch
     timed_launch(c, K_SHADE, [&] { launch_finish_shade_uber(cfg, c->sc, c->st, fp); });
@@ -568,7 +570,7 @@ void mirt_default_params(MirtParams *out) {
   out->seed = 0x5EED0000u;
   out->nee = 0;
   out->adaptive = 0;
-  out->reserved = 0;
+  out->stage_kernels = 0;
 }
 
 int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {

@@ -1,6 +1,8 @@
-// classic.hip — the per-material shading path: the connect (shadow) kernel
-// with light sampling, and one kernel per material kind (Lambertian, Metallic,
-// Dielectric, Emissive), each popping its own queue.
+// classic.hip — the per-material shading path: the extend epilogue with light
+// sampling, the connect (shadow) kernel, and the material kinds (Lambertian,
+// Metallic, Dielectric, Emissive) — as one kernel behind the connect stage, or,
+// with MirtParams.stage_kernels, as one kernel per material popping its own
+// queue, the way the archive frame dispatches them.
 //
 // Restates shaders/archive/{shadow,light,material,lambertian,metallic,
 // dielectric,emissive}.slang on top of the live traversal.  Deliberate
@@ -20,6 +22,21 @@
 //     stage (archive/dielectric.slang:66 recomputes it from the already
 //     flipped normal, which always yields "front") and multiplies the
 //     throughput by the albedo (archive/dielectric.slang:91 assigns it).
+//
+// What a slot's records hold between the stages of a frame with light sampling
+// (DRay, DHit, DShadow of layout.h, as quarters of 16 bytes):
+//   after k_extend            hit[0] = u, v, triangle, instance (or kMissInst)
+//   after k_extend_finish     ray[0] = shadow-ray origin xyz, incoming direction x
+//                             ray[1] = incoming direction y z, then the hit's texture coordinate in scenes
+//                                      with textures (else the exclusion ids, no longer needed)
+//                             hit[0] = world position xyz, instance | front_face << 31
+//                             hit[1] = world normal xyz, b of the light sample
+//                             shadow[0] = direction to the light sample xyz, its probability (0: none shot)
+//                             shadow[1] = light instance, distance to the sample (negative: none shot),
+//                                         light triangle, a of the light sample
+//   after k_connect           shadow[0].w = 0 where the shadow ray was stopped
+// so the walk's refill — single lanes, with the rest of the wave waiting — reads three quarters and
+// computes nothing, and everything that is arithmetic runs in the streaming kernels.
 #include <float.h>
 
 #include "device_util.h"
@@ -103,83 +120,208 @@ __device__ __forceinline__ v3 lambert_brdf(v3 albedo, v3 wi, v3 wo, v3 n) {
 }
 __device__ __forceinline__ float lambert_pdf(v3 wi, v3 n) { return fmax_nn(0.0f, dot3(wi, n)) / 3.1415f; }
 
+// ------------------------------------------------- extend epilogue + light sample
+// get_light_sample / tri_sample / tri_pdf (archive/light.slang:14-81) and the shadow ray of shadowMain
+// (archive/shadow.slang:63-121) for a hit at `hpos` with the normal `nf` facing the incoming ray: light
+// instance and face (two draws), a point on the face (two draws).
+struct LightSample {
+  v3 orig, scatter;   // the shadow ray
+  float dist;         // to the sample; negative when the sample lies behind the surface (nothing is shot)
+  float prob;         // solid-angle probability of the sample, 0 when nothing is shot
+  uint32_t inst, prim;  // the light and its sampled triangle (the shadow ray must not stop at it)
+  float a, b;         // where on the triangle the sample lies
+};
+__device__ __forceinline__ LightSample sample_light(const DScene &sc, Rng &rng, v3 hpos, v3 nf) {
+  LightSample ls;
+  ls.orig = add3(hpos, scale3(nf, 1e-3f));
+  const float r1 = rng_next(rng);
+  const float r2 = rng_next(rng);
+  uint32_t li = (uint32_t)__builtin_floorf(r1 * (float)sc.n_lights);
+  if (li >= sc.n_lights) li = sc.n_lights - 1u;  // r1 can be exactly 1
+  ls.inst = sc.lights[li];
+  const DInst *inst = &sc.inst[ls.inst];
+  const uint32_t n_faces = inst->root_count;
+  uint32_t fi = (uint32_t)__builtin_floorf(r2 * (float)n_faces);
+  if (fi >= n_faces) fi = n_faces - 1u;
+  ls.prim = inst->root_start + fi;
+  const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + ls.prim);
+  const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
+  const v3 p0 = V3(a0.x, a0.y, a0.z), e1 = V3(a1.x, a1.y, a1.z), e2 = V3(a2.x, a2.y, a2.z);
+  float a = rng_next(rng);
+  float b = rng_next(rng);
+  if (a + b > 1.0f) {
+    a = 1.0f - a;
+    b = 1.0f - b;
+  }
+  ls.a = a;
+  ls.b = b;
+  const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
+  const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
+  const float area = 0.5f * length3(cr);
+  const float tri_pdf = area > 0.0f ? 1.0f / area : 1.0f;
+  const float sample_prob = tri_pdf * (1.0f / (float)(sc.n_lights * n_faces));
+  const v3 light_n = normalize3(cr);
+  const v3 d = sub3(sample_pos, ls.orig);
+  const float shadow_t = length3(d);
+  ls.scatter = normalize3(d);
+  const bool shoot = dot3(ls.scatter, nf) > 0.0f;
+  const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(ls.scatter)));
+  ls.prob = shoot ? prob : 0.0f;
+  ls.dist = shoot ? shadow_t : -1.0f;
+  return ls;
+}
+
+// The extend epilogue of per-material shading with light sampling (shaders/ray_extend.slang:34-50 with the
+// bounce count and routing of archive/extension.slang:94-101), one thread per entry of the extension queue:
+// a miss adds the sky and ends the path; a hit gets its world-space record, loses one bounce and — with
+// bounces left — draws its light sample here, where every lane of a wave has an entry, and goes to the
+// connect queue with the shadow ray ready in its records (the table at the top of this file).
+// (Uber shading does its epilogue inside k_finish_shade_uber, per-material shading without light sampling
+// inside k_finish_shade_classic.)
+//
+// RESPAWN: a path that ends here (sky, out of bounces) is accumulated and its slot takes the next sample at
+// once, as in k_finish_shade_uber<true>.
+template <bool RESPAWN>
+__global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *ext = st.qdata[Q_EXT0 + par];
+  const uint32_t count = st.qcount[Q_EXT0 + par];
+  // a path that ends goes to the terminate queue (RESPAWN: its slot, respawned, to the next frame's extension
+  // queue); a hit goes to the connect queue
+  const int q0 = RESPAWN ? Q_EXT0 + (int)(par ^ 1u) : Q_TERM0 + (int)(par ^ 1u);
+  __shared__ BlockPush2 sh;
+  __shared__ BlockReserve shr;
+  CamBasis cb;
+  if (RESPAWN) cb = cam_basis(fp.cam);
+  unsigned long long finished = 0, spawned = 0;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
+    const uint32_t i = base + threadIdx.x;
+    const bool fin = i < count;
+    uint32_t slot = 0;
+    bool hit = false;
+    float4 end_rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t end_src = kNoSample;
+    bool have_end = false;
+    if (fin) {
+      slot = ext[i];
+      float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+      const float4 raw = h4[0];
+      BestHit best;
+      best.u = raw.x;
+      best.v = raw.y;
+      best.t = 0.0f;
+      best.prim = __float_as_uint(raw.z);
+      best.inst = __float_as_uint(raw.w);
+      if (best.inst == kMissInst) {
+        // rad += throughput * sky
+        float4 a = path_q(st, slot, 0u);
+        const float4 b = path_q(st, slot, 1u);
+        const float sky = fp.p.sky_radiance;
+        a.x = a.x + b.x * sky;
+        a.y = a.y + b.y * sky;
+        a.z = a.z + b.z * sky;
+        if (RESPAWN) {
+          end_rad = a;
+          end_src = __float_as_uint(b.w);
+          have_end = true;
+        } else {
+          path_q(st, slot, 0u) = a;
+        }
+      } else {
+        hit = true;
+        float4 *r4 = reinterpret_cast<float4 *>(st.ray + slot);
+        const float4 ra = r4[0], rb = r4[1];
+        v3 hp, hn;
+        uint32_t ff;
+        finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
+        // archive/extension.slang:94-101: a hit costs one bounce; out of
+        // bounces means terminate without shading
+        uint32_t &pb = path_w(st, slot, 3u);
+        const uint32_t bounces = pb - 1u;
+        pb = bounces;
+        if (bounces == 0u) {
+          hit = false;
+        } else {
+          const float sgn = ff != 0u ? 1.0f : -1.0f;
+          Rng rng = load_rng(st, slot);
+          const LightSample ls = sample_light(sc, rng, hp, V3(hn.x * sgn, hn.y * sgn, hn.z * sgn));
+          store_rng(st, slot, rng);
+          float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
+          sh4[0] = make_float4(ls.scatter.x, ls.scatter.y, ls.scatter.z, ls.prob);
+          sh4[1] = make_float4(__uint_as_float(ls.inst), ls.dist, __uint_as_float(ls.prim), ls.a);
+          h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
+          h4[1] = make_float4(hn.x, hn.y, hn.z, ls.b);
+          r4[0] = make_float4(ls.orig.x, ls.orig.y, ls.orig.z, ra.w);
+          if (sc.tri_uv != nullptr) {
+            // the material's texture coordinate rides in the ray's two exclusion words,
+            // which nothing reads between this kernel and the material's own store
+            float tu, tv;
+            hit_uv(sc, best, tu, tv);
+            r4[1] = make_float4(rb.x, rb.y, tu, tv);
+          }
+        }
+      }
+      if (RESPAWN && !hit && !have_end) {
+        end_rad = path_q(st, slot, 0u);
+        end_src = path_w(st, slot, 7u);
+      }
+    }
+    int r = !fin ? -1 : (!hit ? 0 : 1);
+    if (RESPAWN) {
+      const bool done = fin && !hit;
+      if (done) {
+        accumulate_sample(st, fp, end_src, end_rad);
+        finished++;
+      }
+      const unsigned long long si = block_reserve(shr, st.sample_index, done);
+      if (done && si < fp.sample_limit) {
+        spawn_sample(st, fp, cb, slot, si);
+        spawned++;
+      } else if (done) {
+        path_w(st, slot, 7u) = kNoSample;  // the slot retires
+        r = -1;
+      }
+    }
+    block_push2(sh, &st.qcount[q0], st.qdata[q0], r == 0, &st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], r > 0, slot);
+  }
+  if (RESPAWN) {
+    for (int off = 32; off > 0; off >>= 1) {
+      finished += __shfl_down(finished, off);
+      spawned += __shfl_down(spawned, off);
+    }
+    if (lane_id() == 0u) {
+      if (finished) atomicAdd(&st.stats[S_FINISHED], finished);
+      if (spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- connect
-// shadowMain (archive/shadow.slang:63-139) + get_light_sample / tri_sample /
-// tri_pdf (archive/light.slang:14-81).  Pops the connect queue, traces the
-// shadow ray as an any-hit query, writes the slot's ShadowData and routes the
-// slot to the queue of its hit material.
+// The visibility query of shadowMain (archive/shadow.slang:100-121): pops the connect queue and traces the
+// shadow ray k_extend_finish left in the slot's records as an any-hit query.  A slot whose light sample
+// lies behind its surface traces nothing: it gets a ray that cannot hit anything (tmax < 0 rejects the TLAS
+// root) and is not counted.  The verdict: the sample's probability is cleared where the ray was stopped.
 template <bool COUNT>
 __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams fp) {
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
   LaneCounts lc;
   unsigned long long traced = 0;
-
-  // Light sampling happens when the slot is fetched.  A slot whose sample lies
-  // behind its surface traces nothing: it gets a ray that cannot hit anything
-  // (tmax < 0 rejects the TLAS root) and is not counted.
   auto fetch = [&](uint32_t slot, RayIn &r) {
-    const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
-    const float4 ha = h4[0], hb = h4[1];
-    const uint32_t inst_ff = __float_as_uint(ha.w);
-    const float sgn = (inst_ff >> 31) != 0u ? 1.0f : -1.0f;
-    const v3 nf = V3(hb.x * sgn, hb.y * sgn, hb.z * sgn);
-    const v3 orig = add3(V3(ha.x, ha.y, ha.z), scale3(nf, 1e-3f));
-    Rng rng = load_rng(st, slot);
-    // light instance and face (two draws), then a point on the face (two draws)
-    const float r1 = rng_next(rng);
-    const float r2 = rng_next(rng);
-    uint32_t li = (uint32_t)__builtin_floorf(r1 * (float)sc.n_lights);
-    if (li >= sc.n_lights) li = sc.n_lights - 1u;  // r1 can be exactly 1
-    const uint32_t light_inst = sc.lights[li];
-    const DInst *inst = &sc.inst[light_inst];
-    const uint32_t n_faces = inst->root_count;
-    uint32_t fi = (uint32_t)__builtin_floorf(r2 * (float)n_faces);
-    if (fi >= n_faces) fi = n_faces - 1u;
-    const uint32_t light_prim = inst->root_start + fi;
-    const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + light_prim);
-    const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
-    const v3 p0 = V3(a0.x, a0.y, a0.z), e1 = V3(a1.x, a1.y, a1.z), e2 = V3(a2.x, a2.y, a2.z);
-    float a = rng_next(rng);
-    float b = rng_next(rng);
-    if (a + b > 1.0f) {
-      a = 1.0f - a;
-      b = 1.0f - b;
-    }
-    store_rng(st, slot, rng);
-    if (sc.tri_uv != nullptr) {
-      // scenes with textures: where on which light triangle the sample lies rides to k_connect_finish
-      // in the ray record's origin, which nothing reads between the traversal and the material kernel
-      reinterpret_cast<float *>(st.ray + slot)[0] = a;
-      reinterpret_cast<float *>(st.ray + slot)[1] = b;
-      reinterpret_cast<uint32_t *>(st.ray + slot)[2] = light_prim;
-    }
-    const v3 sample_pos = xform_point(inst->m, add3(add3(p0, scale3(e1, a)), scale3(e2, b)));
-    const v3 cr = cross3(xform_vector(inst->m, e1), xform_vector(inst->m, e2));
-    const float area = 0.5f * length3(cr);
-    const float tri_pdf = area > 0.0f ? 1.0f / area : 1.0f;
-    const float sample_prob = tri_pdf * (1.0f / (float)(sc.n_lights * n_faces));
-    const v3 light_n = normalize3(cr);
-    const v3 d = sub3(sample_pos, orig);
-    const float shadow_t = length3(d);
-    const v3 scatter = normalize3(d);
-    const bool shoot = dot3(scatter, nf) > 0.0f;
-    // what the epilogue needs is parked in the slot's ShadowData
-    float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
-    const float prob = sample_prob * dot3(d, d) / __builtin_fabsf(dot3(light_n, neg3(scatter)));
-    sh4[0] = make_float4(scatter.x, scatter.y, scatter.z, shoot ? prob : 0.0f);
-    sh4[1] = make_float4(__uint_as_float(light_inst), shoot ? 1.0f : 0.0f, 0.0f, 0.0f);
-    r.pos = orig;
-    r.dir = scatter;
-    r.last_inst = light_inst;
-    r.last_prim = light_prim;
-    r.tmax = shoot ? shadow_t : -1.0f;
+    const float4 o = reinterpret_cast<const float4 *>(st.ray + slot)[0];
+    const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
+    const float4 s0 = sh4[0], s1 = sh4[1];
+    r.pos = V3(o.x, o.y, o.z);
+    r.dir = V3(s0.x, s0.y, s0.z);
+    r.last_inst = __float_as_uint(s1.x);
+    r.last_prim = __float_as_uint(s1.z);
+    r.tmax = s1.y;
     r.payload = slot;
-    if (shoot) traced++;
+    if (!(s1.y < 0.0f)) traced++;
   };
-  // the verdict joins what fetch parked; k_connect_finish does the rest
   auto finish = [&](bool fin, uint32_t slot, bool occluded, float, const BestHit &) {
-    if (fin) reinterpret_cast<float *>(st.shadow + slot)[7] = occluded ? 1.0f : 0.0f;
+    if (fin && occluded) reinterpret_cast<float *>(st.shadow + slot)[3] = 0.0f;
   };
   trace_engine<true, COUNT>(sc, WorkSource{&st.qcount[W_CONNECT], count, cq, nullptr, nullptr}, lc, fetch, finish);
   if (COUNT) flush_counts(st.stats, S_CON_TLAS, lc);
@@ -188,9 +330,34 @@ __global__ MIRT_ENGINE_BOUNDS void k_connect(DScene sc, DState st, DFrameParams 
   if (lane_id() == 0u && traced) atomicAdd(&st.stats[S_CONNECT_RAYS], traced);
 }
 
-// The epilogue of shadowMain (archive/shadow.slang:122-139), one thread per
-// entry of the connect queue: the slot's ShadowData from the parked sample and
-// the any-hit verdict, then the slot goes to the queue of its hit material.
+// The radiance of the light sample of `slot` (the epilogue of shadowMain, archive/shadow.slang:122-139):
+// the light's emission, times its emissive texture at the sampled point when it has one.  `s1` is the
+// slot's shadow[1] quarter, `b` rides in hit[1].w.
+__device__ __forceinline__ v3 light_radiance(const DScene &sc, float4 s1, float b) {
+  const uint32_t light_inst = __float_as_uint(s1.x);
+  const DInst *linst = &sc.inst[light_inst];
+  if (linst->kind != MIRT_MAT_EMISSIVE) return V3(0.0f, 0.0f, 0.0f);
+  const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
+  v3 rad = V3(e[0], e[1], e[2]);
+  const uint32_t tex = sc.tri_uv != nullptr ? sc.mat[linst->material].tex[1] : 0u;
+  if (tex != 0u) {
+    BestHit lb;
+    lb.t = 0.0f;
+    lb.u = s1.w;
+    lb.v = b;
+    lb.prim = __float_as_uint(s1.z);
+    lb.inst = light_inst;
+    float tu, tv;
+    hit_uv(sc, lb, tu, tv);
+    const v3 c = tex_sample(sc, tex, tu, tv);
+    rad = V3(rad.x * c.x, rad.y * c.y, rad.z * c.z);
+  }
+  return rad;
+}
+
+// MirtParams.stage_kernels: the routing pass behind the connect kernel, one thread per entry of the
+// connect queue — the slot's ShadowData is completed (shadow[1] = the light sample's radiance) and the slot
+// goes to the queue of its hit material.
 __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DState st, DFrameParams fp) {
   // queues 0..3: the four material queues in QueueId order; 4: terminate
   __shared__ BlockPushN<5> sh;
@@ -208,36 +375,12 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
     if (i < count) {
       slot = cq[i];
       float4 *sh4 = reinterpret_cast<float4 *>(st.shadow + slot);
-      float4 s0 = sh4[0];
-      const float4 parked = sh4[1];  // light instance, shoot flag, light triangle, occluded flag
-      const uint32_t light_inst = __float_as_uint(parked.x);
-      float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (parked.y != 0.0f && parked.w == 0.0f) {
-        const DInst *linst = &sc.inst[light_inst];
-        if (linst->kind == MIRT_MAT_EMISSIVE) {
-          const float *e = sc.emissive + 4 * (size_t)linst->kind_data;
-          s1 = make_float4(e[0], e[1], e[2], 0.0f);
-          const uint32_t tex = sc.tri_uv != nullptr ? sc.mat[linst->material].tex[1] : 0u;
-          if (tex != 0u) {
-            // an emissive texture on the light: the texel at the sampled point
-            BestHit lb;
-            lb.t = 0.0f;
-            lb.u = reinterpret_cast<const float *>(st.ray + slot)[0];
-            lb.v = reinterpret_cast<const float *>(st.ray + slot)[1];
-            lb.prim = reinterpret_cast<const uint32_t *>(st.ray + slot)[2];
-            lb.inst = light_inst;
-            float tu, tv;
-            hit_uv(sc, lb, tu, tv);
-            const v3 c = tex_sample(sc, tex, tu, tv);
-            s1 = make_float4(s1.x * c.x, s1.y * c.y, s1.z * c.z, 0.0f);
-          }
-        }
-      } else {
-        s0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      }
-      sh4[0] = s0;
-      sh4[1] = s1;
-      const uint32_t inst_ff = __float_as_uint(reinterpret_cast<const float4 *>(st.hit + slot)[0].w);
+      const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+      const float4 s0 = sh4[0], s1 = sh4[1];
+      v3 rad = V3(0.0f, 0.0f, 0.0f);
+      if (s0.w > 0.0f) rad = light_radiance(sc, s1, h4[1].w);
+      sh4[1] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+      const uint32_t inst_ff = __float_as_uint(h4[0].w);
       const uint32_t kind = sc.inst[inst_ff & 0x7FFFFFFFu].kind;
       // no material (archive/logic.slang:171-174): the path ends here
       route = kind == MIRT_MAT_NONE ? 4 : (int)kind - (int)MIRT_MAT_LAMBERTIAN;
@@ -248,10 +391,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_connect_finish(DScene sc, DSta
 
 // One shade event of material kind KIND for the slot whose state is in `s` (process_material and the four
 // material files of shaders/archive): radiance, throughput and stream state are updated in `s`, the bounce ray
-// comes back in new_pos / new_dir.  Returns whether the path goes on.  `use_shadow`: the connect stage ran and
-// left the slot's ShadowData (light sampling).
+// comes back in new_pos / new_dir.  Returns whether the path goes on.  `use_shadow`: the connect stage ran; `sdw`
+// is then the slot's ShadowData — direction to the light sample and its probability (0: none, or not visible),
+// `light_rad` the sample's radiance.
 template <int KIND>
-__device__ __forceinline__ bool shade_material(const DScene &sc, const DState &st, uint32_t slot, SlotIn &s, bool use_shadow,
+__device__ __forceinline__ bool shade_material(const DScene &sc, SlotIn &s, bool use_shadow, float4 sdw, v3 light_rad,
                                                v3 &new_pos, v3 &new_dir) {
   const DInst *inst = &sc.inst[s.inst];
   new_pos = s.hpos;
@@ -283,11 +427,9 @@ __device__ __forceinline__ bool shade_material(const DScene &sc, const DState &s
     (void)rng_next(s.rng);  // archive/material.slang:91-92
     alive = true;
     if (use_shadow) {
-      const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
-      const float4 s0 = sh4[0], s1 = sh4[1];
-      const float sprob = s0.w;
+      const float sprob = sdw.w;
       if (sprob > 0.0f) {
-        const v3 sdir = V3(s0.x, s0.y, s0.z);
+        const v3 sdir = V3(sdw.x, sdw.y, sdw.z);
         float shadow_weight = 1.0f * sprob;
         shadow_weight /= (1.0f * sprob + 1.0f * lambert_pdf(sdir, nf));
         v3 contrib = thr;
@@ -296,7 +438,7 @@ __device__ __forceinline__ bool shade_material(const DScene &sc, const DState &s
         contrib = scale3(contrib, shadow_weight);
         const float dl = 1.0f * sprob;
         contrib = V3(contrib.x / dl, contrib.y / dl, contrib.z / dl);
-        rad = add3(rad, mul3(V3(s1.x, s1.y, s1.z), contrib));
+        rad = add3(rad, mul3(light_rad, contrib));
       }
     }
     if (scatter_prob > 0.0f) {
@@ -366,7 +508,7 @@ __device__ __forceinline__ bool shade_material(const DScene &sc, const DState &s
 }
 
 // ------------------------------------------------------- material kernels
-// Common frame of the four kernels: pop `queue`, shade, push to the next
+// MirtParams.stage_kernels — common frame of the four kernels: pop `queue`, shade, push to the next
 // frame's extension queue (alive) or terminate queue.
 #ifndef MIRT_MATERIAL_WAVES
 #define MIRT_MATERIAL_WAVES 4
@@ -388,7 +530,14 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
       SlotIn s;
       (void)load_slot<false>(sc, st, slot, s);
       v3 new_pos, new_dir;
-      alive = shade_material<KIND>(sc, st, slot, s, true, new_pos, new_dir);  // the connect kernel ran and left ShadowData
+      // the connect stage ran and left ShadowData (only the Lambertian combination reads it)
+      float4 sdw = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lrad = sdw;
+      if (KIND == MIRT_MAT_LAMBERTIAN) {
+        const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
+        sdw = sh4[0];
+        lrad = sh4[1];
+      }
+      alive = shade_material<KIND>(sc, s, true, sdw, V3(lrad.x, lrad.y, lrad.z), new_pos, new_dir);
       store_slot(st, slot, s, new_pos, new_dir);
     }
     block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
@@ -402,7 +551,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_material(
 // the traversal's result and the path record in registers between the two — no routing pass, no material
 // queues, no hit-record round trip.  A wave whose lanes hit different kinds of material runs their branches one
 // after the other; each is a few dozen instructions against the dozen scattered memory requests a slot costs.
-// The four k_material kernels stay for light sampling, where the connect stage sits between the two halves.
+// (With light sampling the connect stage sits between the two halves: k_extend_finish, k_connect, k_connect_shade.)
 //
 // RESPAWN: a path that ends here — sky, out of bounces, no material, absorbed by its material — is
 // accumulated and its slot takes the render call's next sample at once (as in k_finish_shade_uber<true>).
@@ -452,15 +601,104 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
           if (!RESPAWN) path_q(st, slot, 0u) = s.pa;
         } else {
           v3 new_pos, new_dir;
-          if (kind == MIRT_MAT_LAMBERTIAN) alive = shade_material<MIRT_MAT_LAMBERTIAN>(sc, st, slot, s, false, new_pos, new_dir);
-          else if (kind == MIRT_MAT_METALLIC) alive = shade_material<MIRT_MAT_METALLIC>(sc, st, slot, s, false, new_pos, new_dir);
-          else if (kind == MIRT_MAT_DIELECTRIC) alive = shade_material<MIRT_MAT_DIELECTRIC>(sc, st, slot, s, false, new_pos, new_dir);
-          else alive = shade_material<MIRT_MAT_EMISSIVE>(sc, st, slot, s, false, new_pos, new_dir);
+          const float4 no_shadow = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          if (kind == MIRT_MAT_LAMBERTIAN) alive = shade_material<MIRT_MAT_LAMBERTIAN>(sc, s, false, no_shadow, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+          else if (kind == MIRT_MAT_METALLIC) alive = shade_material<MIRT_MAT_METALLIC>(sc, s, false, no_shadow, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+          else if (kind == MIRT_MAT_DIELECTRIC) alive = shade_material<MIRT_MAT_DIELECTRIC>(sc, s, false, no_shadow, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+          else alive = shade_material<MIRT_MAT_EMISSIVE>(sc, s, false, no_shadow, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
           shaded++;
           rad = s.pa;
           source = __float_as_uint(s.pb.w);
           if (alive || !RESPAWN) store_slot(st, slot, s, new_pos, new_dir);
         }
+      }
+    }
+    if (RESPAWN) {
+      const bool done = active && !alive;
+      if (done) {
+        accumulate_sample(st, fp, source, rad);
+        finished++;
+      }
+      const unsigned long long si = block_reserve(shr, st.sample_index, done);
+      if (done && si < fp.sample_limit) {
+        spawn_sample(st, fp, cb, slot, si);
+        spawned++;
+        alive = true;
+      } else if (done) {
+        path_w(st, slot, 7u) = kNoSample;  // the slot retires
+      }
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
+                  false, slot);
+    } else {
+      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
+                  &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    shaded += __shfl_down(shaded, off);
+    if (RESPAWN) {
+      finished += __shfl_down(finished, off);
+      spawned += __shfl_down(spawned, off);
+    }
+  }
+  if (lane_id() == 0u) {
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+  }
+}
+
+// Light sampling, behind the connect kernel, in ONE pass over the connect queue: the epilogue of shadowMain
+// (archive/shadow.slang:122-139: the visible sample's radiance) and the hit material's shade event
+// (process_material, archive/material.slang:17-139), with the ShadowData in registers between the two — no
+// routing pass, no material queues, no second trip of the ShadowData through memory.  A wave whose lanes hit
+// different kinds of material runs their branches one after the other, as in k_finish_shade_classic.
+//
+// RESPAWN: a path that ends here — no material, absorbed by its material — is accumulated and its slot
+// takes the render call's next sample at once.
+template <bool RESPAWN>
+__global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_connect_shade(DScene sc, DState st, DFrameParams fp) {
+  __shared__ BlockPush2 sh;
+  __shared__ BlockReserve shr;
+  const uint32_t par = fp.frame & 1u;
+  const uint32_t *cq = st.qdata[Q_CONNECT];
+  const uint32_t count = st.qcount[Q_CONNECT];
+  CamBasis cb;
+  if (RESPAWN) cb = cam_basis(fp.cam);
+  unsigned long long shaded = 0, finished = 0, spawned = 0;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
+    const uint32_t i = base + threadIdx.x;
+    const bool active = i < count;
+    uint32_t slot = 0;
+    bool alive = false;
+    float4 rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // of a path that ends here
+    uint32_t source = kNoSample;
+    if (active) {
+      slot = cq[i];
+      const float4 *sh4 = reinterpret_cast<const float4 *>(st.shadow + slot);
+      const float4 sdw = sh4[0], s1 = sh4[1];
+      SlotIn s;
+      (void)load_slot<false>(sc, st, slot, s);
+      const uint32_t kind = sc.inst[s.inst].kind;
+      rad = s.pa;
+      source = __float_as_uint(s.pb.w);
+      if (kind != MIRT_MAT_NONE) {  // no material (archive/logic.slang:171-174): the path ends as it is
+        v3 new_pos, new_dir;
+        if (kind == MIRT_MAT_LAMBERTIAN) {
+          v3 lrad = V3(0.0f, 0.0f, 0.0f);
+          if (sdw.w > 0.0f) lrad = light_radiance(sc, s1, reinterpret_cast<const float4 *>(st.hit + slot)[1].w);
+          alive = shade_material<MIRT_MAT_LAMBERTIAN>(sc, s, true, sdw, lrad, new_pos, new_dir);
+        } else if (kind == MIRT_MAT_METALLIC) {
+          alive = shade_material<MIRT_MAT_METALLIC>(sc, s, true, sdw, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+        } else if (kind == MIRT_MAT_DIELECTRIC) {
+          alive = shade_material<MIRT_MAT_DIELECTRIC>(sc, s, true, sdw, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+        } else {
+          alive = shade_material<MIRT_MAT_EMISSIVE>(sc, s, true, sdw, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
+        }
+        shaded++;
+        rad = s.pa;
+        if (alive || !RESPAWN) store_slot(st, slot, s, new_pos, new_dir);
       }
     }
     if (RESPAWN) {
@@ -505,17 +743,28 @@ void launch_finish_shade_classic(const LaunchCfg &cfg, const DScene &sc, const D
   else hipLaunchKernelGGL((k_finish_shade_classic<false>), stream_grid(cfg, k_finish_shade_classic<false>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
+void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  const dim3 block(kStreamBlock);
+  if (fp.respawn) hipLaunchKernelGGL((k_extend_finish<true>), stream_grid(cfg, k_extend_finish<true>), block, 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_extend_finish<false>), stream_grid(cfg, k_extend_finish<false>), block, 0, cfg.stream, sc, st, fp);
+}
+
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (fp.counting) hipLaunchKernelGGL((k_connect<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
   else hipLaunchKernelGGL((k_connect<false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
-  hipLaunchKernelGGL(k_connect_finish, stream_grid(cfg, k_connect_finish), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+}
+
+void launch_connect_shade(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
+  if (fp.respawn) hipLaunchKernelGGL((k_connect_shade<true>), stream_grid(cfg, k_connect_shade<true>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
+  else hipLaunchKernelGGL((k_connect_shade<false>), stream_grid(cfg, k_connect_shade<false>), dim3(kStreamBlock), 0, cfg.stream, sc, st, fp);
 }
 
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  // the four per-material kernels, one queue each (archive frame order:
+  // the routing pass, then the four per-material kernels, one queue each (archive frame order:
   // src/app.rs:402-410 dispatches every material phase each frame)
   const dim3 block(kStreamBlock);
+  hipLaunchKernelGGL(k_connect_finish, stream_grid(cfg, k_connect_finish), block, 0, cfg.stream, sc, st, fp);
   hipLaunchKernelGGL((k_material<MIRT_MAT_LAMBERTIAN>), stream_grid(cfg, k_material<MIRT_MAT_LAMBERTIAN>), block, 0, cfg.stream, sc, st, fp);
   hipLaunchKernelGGL((k_material<MIRT_MAT_METALLIC>), stream_grid(cfg, k_material<MIRT_MAT_METALLIC>), block, 0, cfg.stream, sc, st, fp);
   hipLaunchKernelGGL((k_material<MIRT_MAT_DIELECTRIC>), stream_grid(cfg, k_material<MIRT_MAT_DIELECTRIC>), block, 0, cfg.stream, sc, st, fp);

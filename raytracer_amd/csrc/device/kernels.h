@@ -127,11 +127,16 @@ void launch_sample_ordered(const LaunchCfg &cfg, const DScene &sc, const DState 
 // flags[s] |= 1 where the standard error of source s's mean has fallen to rel_threshold of the mean
 void launch_adapt_update(const LaunchCfg &cfg, const DState &st, double threshold_squared, uint32_t min_samples);
 void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
-// per-material shading: the extend epilogue (hit records, bounce count, routing to the material queues)
+// per-material shading with light sampling: the extend epilogue (hit records, bounce count, the light sample
+// and its shadow ray, routing to the connect queue)
 void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 // uber shading: the extend epilogue and shadeMain in one kernel
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// the any-hit walk of the shadow rays on the connect queue
 void launch_connect(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// behind it: the light sample's radiance and the hit material's shade event in one kernel ...
+void launch_connect_shade(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
+// ... or (MirtParams.stage_kernels) a routing pass and one kernel per material, each popping its own queue
 void launch_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);
 // per-material shading without light sampling: the extend epilogue and the hit material's shade event in one kernel
 void launch_finish_shade_classic(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp);

@@ -352,128 +352,6 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&st.stats[S_EXTEND_RAYS], (unsigned long long)count);
 }
 
-// The extend epilogue of per-material shading (shaders/ray_extend.slang:34-50
-// with the bounce count and routing of archive/extension.slang:94-101), one
-// thread per entry of the extension queue: a miss adds the sky and ends the
-// path, a hit gets its world-space record and goes to the connect queue or to
-// the queue of its material.  (Uber shading does this inside
-// k_finish_shade_uber.)
-//
-// RESPAWN: a path that ends here (sky, out of bounces, no material) is
-// accumulated and its slot takes the next sample at once, as in
-// k_finish_shade_uber<true>; paths that end in a material kernel still go
-// through the terminate queue and the sample kernel.
-// (Without light sampling this kernel is not used: k_finish_shade_classic does the epilogue and the material
-// in one pass.)
-template <bool RESPAWN>
-__global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DState st, DFrameParams fp) {
-  const uint32_t par = fp.frame & 1u;
-  const uint32_t *ext = st.qdata[Q_EXT0 + par];
-  const uint32_t count = st.qcount[Q_EXT0 + par];
-  // a path that ends goes to the terminate queue (RESPAWN: its slot, respawned, to the next frame's extension
-  // queue); a hit goes to the connect queue
-  const int q0 = RESPAWN ? Q_EXT0 + (int)(par ^ 1u) : Q_TERM0 + (int)(par ^ 1u);
-  __shared__ BlockPush2 sh;
-  __shared__ BlockReserve shr;
-  CamBasis cb;
-  if (RESPAWN) cb = cam_basis(fp.cam);
-  unsigned long long finished = 0, spawned = 0;
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
-    const uint32_t i = base + threadIdx.x;
-    const bool fin = i < count;
-    uint32_t slot = 0;
-    bool hit = false;
-    uint32_t route = 0;  // queue of the hit material
-    float4 end_rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t end_src = kNoSample;
-    bool have_end = false;
-    if (fin) {
-      slot = ext[i];
-      float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
-      const float4 raw = h4[0];
-      BestHit best;
-      best.u = raw.x;
-      best.v = raw.y;
-      best.t = 0.0f;
-      best.prim = __float_as_uint(raw.z);
-      best.inst = __float_as_uint(raw.w);
-      if (best.inst == kMissInst) {
-        // rad += throughput * sky
-        float4 a = path_q(st, slot, 0u);
-        const float4 b = path_q(st, slot, 1u);
-        const float sky = fp.p.sky_radiance;
-        a.x = a.x + b.x * sky;
-        a.y = a.y + b.y * sky;
-        a.z = a.z + b.z * sky;
-        if (RESPAWN) {
-          end_rad = a;
-          end_src = __float_as_uint(b.w);
-          have_end = true;
-        } else {
-          path_q(st, slot, 0u) = a;
-        }
-      } else {
-        hit = true;
-        {
-          const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
-          const float4 ra = r4[0], rb = r4[1];
-          v3 hp, hn;
-          uint32_t ff;
-          finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
-          h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
-          h4[1] = make_float4(hn.x, hn.y, hn.z, __uint_as_float(best.prim));
-          if (sc.tri_uv != nullptr) {
-            // the material kernel's texture coordinate rides in the ray's two exclusion words,
-            // which nothing reads between this kernel and the material kernel's own store
-            float tu, tv;
-            hit_uv(sc, best, tu, tv);
-            reinterpret_cast<float4 *>(st.ray + slot)[1] = make_float4(rb.x, rb.y, tu, tv);
-          }
-        }
-        // archive/extension.slang:94-101: a hit costs one bounce; out of
-        // bounces means terminate without shading
-        uint32_t &pb = path_w(st, slot, 3u);
-        const uint32_t bounces = pb - 1u;
-        pb = bounces;
-        if (bounces == 0u) hit = false;
-        else route = Q_CONNECT;
-      }
-      if (RESPAWN && !hit && !have_end) {
-        end_rad = path_q(st, slot, 0u);
-        end_src = path_w(st, slot, 7u);
-      }
-    }
-    int r = !fin ? -1 : (!hit ? 0 : (int)(route - Q_CONNECT) + 1);
-    if (RESPAWN) {
-      const bool done = fin && !hit;
-      if (done) {
-        accumulate_sample(st, fp, end_src, end_rad);
-        finished++;
-      }
-      const unsigned long long si = block_reserve(shr, st.sample_index, done);
-      if (done && si < fp.sample_limit) {
-        spawn_sample(st, fp, cb, slot, si);
-        spawned++;
-      } else if (done) {
-        path_w(st, slot, 7u) = kNoSample;  // the slot retires
-        r = -1;
-      }
-    }
-    block_push2(sh, &st.qcount[q0], st.qdata[q0], r == 0, &st.qcount[Q_CONNECT], st.qdata[Q_CONNECT], r > 0, slot);
-  }
-  if (RESPAWN) {
-    for (int off = 32; off > 0; off >>= 1) {
-      finished += __shfl_down(finished, off);
-      spawned += __shfl_down(spawned, off);
-    }
-    if (lane_id() == 0u) {
-      if (finished) atomicAdd(&st.stats[S_FINISHED], finished);
-      if (spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
-    }
-  }
-}
-
 // ------------------------------------------------------------ shade (uber)
 
 // unitDiskSample (shaders/shade.slang:101-109)
@@ -930,12 +808,6 @@ void launch_extend(const LaunchCfg &cfg, const DScene &sc, const DState &st, con
   const dim3 grid(trace_grid_blocks(cfg.num_cus));
   if (fp.counting) hipLaunchKernelGGL((k_extend<true>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
   else hipLaunchKernelGGL((k_extend<false>), grid, dim3(kEngineBlock), 0, cfg.stream, sc, st, fp);
-}
-
-void launch_extend_finish(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {
-  const dim3 block(kStreamBlock);
-  if (fp.respawn) hipLaunchKernelGGL((k_extend_finish<true>), stream_grid(cfg, k_extend_finish<true>), block, 0, cfg.stream, sc, st, fp);
-  else hipLaunchKernelGGL((k_extend_finish<false>), stream_grid(cfg, k_extend_finish<false>), block, 0, cfg.stream, sc, st, fp);
 }
 
 void launch_finish_shade_uber(const LaunchCfg &cfg, const DScene &sc, const DState &st, const DFrameParams &fp) {

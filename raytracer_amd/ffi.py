@@ -103,7 +103,7 @@ class Params(C.Structure):
     _fields_ = [("max_bounces", C.c_uint32), ("sky_radiance", C.c_float),
                 ("fixed_point_scale", C.c_float), ("exposure", C.c_float),
                 ("shade_mode", C.c_uint32), ("rng_mode", C.c_uint32), ("seed", C.c_uint32),
-                ("nee", C.c_uint32), ("adaptive", C.c_uint32), ("reserved", C.c_uint32)]
+                ("nee", C.c_uint32), ("adaptive", C.c_uint32), ("stage_kernels", C.c_uint32)]
 
 
 class TraversalCounts(C.Structure):

@@ -54,7 +54,7 @@ pub struct MirtParams {
     pub seed: u32,
     pub nee: u32,
     pub adaptive: u32,
-    pub reserved: u32,
+    pub stage_kernels: u32,
 }
 
 #[repr(C)] #[derive(Clone, Copy)]

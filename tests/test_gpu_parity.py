@@ -154,6 +154,56 @@ def test_per_material_kernels_and_connect_rays_config5_small(pt, config_scenes):
     assert ffi.MAT_METALLIC in arrays2["classic_refs"]["kind"].tolist()
 
 
+def test_one_kernel_per_material_behind_the_connect_stage(pt, config_scenes):
+    # MirtParams.stage_kernels: the archive frame's shape — a routing pass and one kernel per material, each
+    # popping its own queue (src/app.rs:402-410) — against the oracle, like the one-kernel default: a budgeted
+    # render, the per-frame call, and the per-frame call with per-slot streams (where the order in which a
+    # slot's stream is drawn from matters: light sample first, then the material)
+    for cfg, W, H, slots in ((5, 128, 72, 3000), (1, 64, 64, 1500)):
+        arrays, info = config_scenes(cfg, dragon_n_u=96, dragon_n_v=24) if cfg == 5 else config_scenes(cfg)
+        sc = po.Scene(arrays)
+        pt.upload_scene(arrays)
+        src = host.make_sample_sources(W, H, info.seed)
+        cam = host.default_camera(W, H)
+        kw = dict(max_bounces=info.max_bounces, seed=info.seed, shade_mode=1, nee=1)
+        oprm = po.default_params(**kw)
+        w4, wcnt, wst = sc.render(cam, src, W, H, oprm, 0, 2)
+        f4, fcnt, fst = sc.step_wavefront(cam, src, W, H, oprm, 0, 11, slots)
+        assert wst.connect_rays > 300 and fst.connect_rays > 300 and fst.finished_samples > 0
+        for stage in (1, 0):
+            pt.create_state(W, H, slots, src, pathtracer.default_params(stage_kernels=stage, **kw))
+            pt.set_camera(cam)
+            pt.stats_reset()
+            pt.render_spp(2)
+            s4, cnt = pt.read_accum()
+            assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4), (cfg, stage)
+            st = pt.stats()
+            assert (st.extend_rays, st.connect_rays, st.shade_events) == (wst.extend_rays, wst.connect_rays, wst.shade_events)
+            pt.reset_accum()
+            pt.create_state(W, H, slots, src, pathtracer.default_params(stage_kernels=stage, **kw))
+            pt.set_camera(cam)
+            pt.stats_reset()
+            pt.step(11)
+            s4, cnt = pt.read_accum()
+            assert np.array_equal(cnt, fcnt) and np.array_equal(s4, f4), (cfg, stage)
+            st = pt.stats()
+            assert (st.extend_rays, st.connect_rays, st.shade_events, st.finished_samples) == (
+                fst.extend_rays, fst.connect_rays, fst.shade_events, fst.finished_samples)
+        # per-slot streams
+        rng = np.random.default_rng(5 + cfg).integers(1000, 2 ** 32, size=(slots, 4), dtype=np.uint64).astype("<u4")
+        okw = dict(rng_mode=ffi.RNG_PER_SLOT, **kw)
+        p4, pcnt, pst = sc.wavefront_per_slot(cam, src, W, H, po.default_params(**okw), rng, 2 ** 62, 13, slots)
+        for stage in (1, 0):
+            pt.create_state(W, H, slots, src, pathtracer.default_params(stage_kernels=stage, **okw))
+            pt.set_camera(cam)
+            pt.set_rng(rng)
+            pt.stats_reset()
+            pt.step(13)
+            s4, cnt = pt.read_accum()
+            assert np.array_equal(cnt, pcnt) and np.array_equal(s4, p4), (cfg, stage)
+            assert pt.stats().connect_rays == pst.connect_rays
+
+
 def test_light_geometry_with_an_inner_root_ignores_its_meaningless_range(pt):
     # start/end of an inner node mean nothing (src/bvh.rs:206): a light whose BLAS
     # root is an inner node is sampled over all triangles of its geometry, whatever

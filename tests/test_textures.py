@@ -145,14 +145,15 @@ def test_textured_scene_matches_the_oracle_in_both_shading_paths():
         assert lit["materials"]["emissive_texture"].max() == 3
         pt.update_instances(lit)  # textures and materials are instance-side data: no geometry upload
         kw = dict(max_bounces=5, seed=21, shade_mode=1, nee=1)
-        pt.create_state(W, H, 2500, src, pathtracer.default_params(**kw))
-        pt.set_camera(cam)
-        pt.stats_reset()
-        pt.render_spp(2)
-        s4, cnt = pt.read_accum()
         w4, wcnt, wst = po.Scene(lit).render(cam, src, W, H, po.default_params(**kw), 0, 2)
-        assert wst.connect_rays > 1000 and pt.stats().connect_rays == wst.connect_rays
-        assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4)
+        for stage in (0, 1):  # the materials in one kernel / in a kernel each behind a routing pass
+            pt.create_state(W, H, 2500, src, pathtracer.default_params(stage_kernels=stage, **kw))
+            pt.set_camera(cam)
+            pt.stats_reset()
+            pt.render_spp(2)
+            s4, cnt = pt.read_accum()
+            assert wst.connect_rays > 1000 and pt.stats().connect_rays == wst.connect_rays
+            assert np.array_equal(cnt, wcnt) and np.array_equal(s4, w4), stage
         untextured = {k: v.copy() for k, v in lit.items()}
         untextured["materials"]["emissive_texture"] = 0
         u4, _, _ = po.Scene(untextured).render(cam, src, W, H, po.default_params(**kw), 0, 2)
