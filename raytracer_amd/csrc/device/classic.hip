@@ -53,6 +53,7 @@ struct SlotIn {
   v3 hpos, hn;  // hit position, normal flipped to face the ray
   uint32_t inst, ff;
   float tu, tv;  // texture coordinate of the hit (scenes with textures only)
+  float hit_w;   // the last word of the world-space hit record (light sampling: b of the light sample)
 };
 
 // RAW: the hit record still holds what the traversal left (u, v, triangle, instance) and the world-space record of extensionMain
@@ -87,6 +88,7 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
     best.inst = __float_as_uint(raw.w);
     finish_hit(sc, s.rdir, best, s.hpos, hn, s.ff);
     s.inst = best.inst;
+    s.hit_w = 0.0f;
     if (sc.tri_uv != nullptr) hit_uv(sc, best, s.tu, s.tv);
   } else {
     const float4 ha = h4[0], hb = h4[1];
@@ -95,6 +97,7 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
     s.ff = inst_ff >> 31;
     s.hpos = V3(ha.x, ha.y, ha.z);
     hn = V3(hb.x, hb.y, hb.z);
+    s.hit_w = hb.w;
   }
   const float sgn = s.ff != 0u ? 1.0f : -1.0f;
   s.hn = V3(hn.x * sgn, hn.y * sgn, hn.z * sgn);
@@ -687,7 +690,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_connect_s
         v3 new_pos, new_dir;
         if (kind == MIRT_MAT_LAMBERTIAN) {
           v3 lrad = V3(0.0f, 0.0f, 0.0f);
-          if (sdw.w > 0.0f) lrad = light_radiance(sc, s1, reinterpret_cast<const float4 *>(st.hit + slot)[1].w);
+          if (sdw.w > 0.0f) lrad = light_radiance(sc, s1, s.hit_w);
           alive = shade_material<MIRT_MAT_LAMBERTIAN>(sc, s, true, sdw, lrad, new_pos, new_dir);
         } else if (kind == MIRT_MAT_METALLIC) {
           alive = shade_material<MIRT_MAT_METALLIC>(sc, s, true, sdw, V3(0.0f, 0.0f, 0.0f), new_pos, new_dir);
