@@ -12,7 +12,8 @@ in, and `config.geometry` says so.
 
 A step renders `--spp-per-step` samples for every pixel through the whole
 pipeline (sample/new_ray -> extend -> shade, to completion) with all inputs
-resident in HBM.  With N > 1 every rank renders its own sample numbers
+resident in HBM; by default that is configuration 3's own 256 samples per pixel, so
+a step is the whole render BASELINE.json names (other configurations: 64).  With N > 1 every rank renders its own sample numbers
 (samples-per-pixel are partitioned, scene replicated: weak scaling) and the
 accumulators are combined by one RCCL all-reduce inside the timed region.
 
@@ -52,7 +53,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=0,
+                    help="samples per pixel one step renders; 0 (default): the configuration's own sample count when "
+                         "that lies in 64..256 — config 3's 256 spp: a step is the whole render BASELINE.json names — "
+                         "else 64")
     ap.add_argument("--paths-per-pixel", type=int, default=32,
                     help="paths in flight (slots of the wavefront state) per pixel")
     ap.add_argument("--config", type=int, default=3)
@@ -271,7 +275,7 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths, classic=False
         "lds_served_triangle_tests_per_launch": tri_lds / launches,
         "lds_served_bytes_equivalent_per_launch": 48 * tri_lds / launches,
         "launch_ms": ext_s * 1e3, "launches": launches,
-        "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "traffic_key": workload,
         "hbm_peak": HBM_PEAK_GBS,
         "hbm_frac": (traffic / ext_s / 1e9 / HBM_PEAK_GBS) if traffic and ext_s > 0 else None,
         # the traffic model in the reference's struct sizes (64 B per node, 160 B per triangle test, 76 B per
@@ -393,6 +397,8 @@ def build_workload(args, geometry):
     H = args.height or info.height
     if args.mode == "step":
         W, H = args.width or 512, args.height or 512
+    if args.spp_per_step <= 0:
+        args.spp_per_step = int(info.spp) if 64 <= int(info.spp) <= 256 else 64
     src = host.make_sample_sources(W, H, info.seed, shuffle=2)
     cam = host.default_camera(W, H)
     params = pathtracer.default_params(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode,
@@ -436,7 +442,8 @@ def replay_counts(pt, ranges):
 
 
 def workload_name(args, W, H, geometry):
-    return f"config{args.config} {W}x{H}" + ("" if geometry == "knot" else f" {geometry}")
+    # (the key of a counter pass in profiles/traffic.json: traffic per launch depends on all of these)
+    return f"config{args.config} {W}x{H} {args.spp_per_step} spp per step" + ("" if geometry == "knot" else f" {geometry}")
 
 
 def secondary_line(args, local_rank):

@@ -43,9 +43,8 @@ for geo in ("knot", "suzanne"):
     b = json.loads(open(os.path.join(out, f"bench_{geo}_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     kx = "k_extend<false>"
     f_kb, f_n = fetch[kx]; w_kb, w_n = write[kx]
-    wl = b["config"]["workload"].split(":")[0] + " " + re.search(r"(\d+x\d+)", b["config"]["workload"]).group(1)
     entries.append({
-     "workload": wl + ("" if geo == "knot" else " " + geo),
+     "workload": b["roofline"]["traffic_key"],  # bench.workload_name(): configuration, size, samples per step, geometry
      "paths_in_flight": b["config"]["paths_in_flight"],
      "measured_at_head": head,
      "device_sources_sha": bench.device_sources_sha(),
