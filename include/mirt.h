@@ -211,7 +211,9 @@ enum { MIRT_SHADE_UBER = 0, MIRT_SHADE_CLASSIC = 1 };
  * the picture; the reference leaves that to the arrival order of its atomics,
  * here the slots that ended in a frame take the next sample numbers in
  * ascending slot order, one of the runs the reference can make and the same
- * on every run.  Single GPU, sample stage on one CU: for comparison runs. */
+ * on every run (the sample stage is then three launches over the whole grid,
+ * within a few per cent of the default's frame time).  One GPU: the streams
+ * belong to slots, so sample numbers cannot be split over devices. */
 enum { MIRT_RNG_PER_SAMPLE = 0, MIRT_RNG_PER_SLOT = 1 };
 
 /* Every literal of the reference kernels that a configuration changes. */
