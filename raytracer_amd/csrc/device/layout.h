@@ -135,7 +135,9 @@ static_assert(sizeof(DHit) == 32, "DHit must be 32 bytes");
 // Measured and not used: the queues list slots in the order paths survive, not in slot order (a render call
 // hands every slot two or three samples and then retires it, so most frames compact), and a scattered slot
 // then costs three cache lines instead of one or two: the uber shade kernel 2.29 -> 2.40 ms per launch, the
-// per-material kernels of config 2 1.65 -> 2.25 ms per frame.
+// per-material kernels of config 2 1.65 -> 2.25 ms per frame.  With 256 samples per pixel and render call
+// (eight samples per slot, queues mostly in slot order) it is the other way round, but barely: the uber kernel
+// 4.14 -> 4.08 ms per launch, 1359 -> 1363 Mrays/s.
 #ifndef MIRT_PATH_PLANES
 #define MIRT_PATH_PLANES 0
 #endif
@@ -150,7 +152,12 @@ struct DPath {
 };
 static_assert(sizeof(DPath) == 48, "DPath must be 48 bytes");
 
-struct DShadow {  // archive ShadowData
+// The connect stage's record of a slot.  First half: archive ShadowData's direction to the light sample and
+// its probability (0: nothing shot, or the shadow ray was stopped).  Second half, as quarters of four words:
+// between the extend epilogue and the material, the light instance, the distance to the sample (negative:
+// nothing shot), the light triangle and the sample's first barycentric; behind the routing pass of
+// MirtParams.stage_kernels, ShadowData's radiance.
+struct DShadow {
   float dx, dy, dz, prob;
   float rx, ry, rz, pad;
 };
