@@ -154,6 +154,7 @@ constexpr bool kLoneLeaf = MIRT_LONE_LEAF != 0;  // a single waiting lane's smal
 #define MIRT_PREFETCH_HK 1
 #endif
 constexpr bool kPrefetchHk = MIRT_PREFETCH_HK != 0;
+
 struct WorkSource {
   uint32_t *counter;  // zeroed before the launch
   uint32_t count;     // number of queue entries
@@ -205,7 +206,7 @@ struct WorkSource {
 #define MIRT_ENGINE_BLOCK 1024u
 #endif
 // Threads per block of every kernel built on the engine.  One 1024-thread block
-// per CU (four waves per SIMD, which is what 97 registers per lane allow): every
+// per CU (four waves per SIMD; the kernels use some 107 of the 128 registers per lane that allows): every
 // wave of the CU shares one copy of the leaf cache, up to kLeafCacheBytes of LDS.
 constexpr uint32_t kEngineBlock = MIRT_ENGINE_BLOCK;
 // blocks below 512 threads would need a copy of the leaf cache each and go without
@@ -320,6 +321,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   uint32_t leaf_start = 0, leaf_count = 0;
   // touched once per instance or per ray
   v3 wpos = V3(0.0f, 0.0f, 0.0f), wdir = V3(1.0f, 1.0f, 1.0f);  // the world-space ray
+  v3 wdinv = V3(1.0f, 1.0f, 1.0f);  // 1 / wdir, kept for the return from an instance (a correctly rounded division is a dozen instructions)
   uint32_t last_inst = 0, last_prim = 0, payload = 0;
   uint32_t tlas_cur = 0, slot_next = 0, slot_stop = 0, cur_inst = 0;  // while in a BLAS: where the TLAS walk stands, the instance
   float best_u = 0.0f, best_v = 0.0f;
@@ -363,7 +365,6 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
       {
         unsigned long long bigmask =
             __ballot((fl & (F_WALK | F_HOLD | F_BLAS)) == (F_WALK | F_HOLD | F_BLAS) && leaf_count >= kCoopLeaf);
-        const bool any_big = bigmask != 0ull;
         MIRT_PH_RESET;
         while (bigmask != 0ull) {
           const int owner = __ffsll((long long)bigmask) - 1;
@@ -471,9 +472,8 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             if ((fl & F_WRAP) == 0u) fl &= ~F_HOLD;
           }
         }
-        // 1/dir is not needed by the scan: rebuilding it here (same operation, same
-        // bits) instead of keeping it frees its registers for the scan
-        if (any_big) cdinv = V3(1.0f / cdir.x, 1.0f / cdir.y, 1.0f / cdir.z);
+        // (1/dir stays in its registers across the scan: the kernel has them to spare at four waves per SIMD, and
+        // rebuilding it, as the engine once did to make room, costs three divisions per service point with a scan)
         MIRT_PH_MARK(7);
       }
 
@@ -647,7 +647,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
               fl &= ~F_BLAS;
               cpos = wpos;
               cdir = wdir;
-              cdinv = V3(1.0f / wdir.x, 1.0f / wdir.y, 1.0f / wdir.z);  // the bits the walk started with
+              cdinv = wdinv;  // the bits the walk started with
               cur = tlas_cur;
               slot_i = slot_next;
               slot_end = slot_stop;
@@ -728,6 +728,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             wpos = cpos = ray.pos;
             wdir = cdir = ray.dir;
             cdinv = V3(1.0f / ray.dir.x, 1.0f / ray.dir.y, 1.0f / ray.dir.z);
+            wdinv = cdinv;
             last_inst = ray.last_inst;
             last_prim = ray.last_prim;
             payload = ray.payload;
