@@ -1760,10 +1760,15 @@ int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group)
   // (the reduction works without, through host staging inside the runtime)
   for (int i = 1; i < n; ++i) {
     if (device_ordinals[i] == device_ordinals[0]) continue;
+    // both ways: the reduction's copies run on the other member's stream and write into member 0's memory
     int can = 0;
     if (hipDeviceCanAccessPeer(&can, device_ordinals[0], device_ordinals[i]) == hipSuccess && can &&
         hipSetDevice(device_ordinals[0]) == hipSuccess)
       (void)hipDeviceEnablePeerAccess(device_ordinals[i], 0);  // "already enabled" is fine
+    can = 0;
+    if (hipDeviceCanAccessPeer(&can, device_ordinals[i], device_ordinals[0]) == hipSuccess && can &&
+        hipSetDevice(device_ordinals[i]) == hipSuccess)
+      (void)hipDeviceEnablePeerAccess(device_ordinals[0], 0);
   }
   (void)hipGetLastError();
   *out_group = g;
@@ -1840,10 +1845,15 @@ int mirt_group_render_spp(mirt_group *g, uint32_t spp) {
     mirt_ctx *c = g->members[i];
     int *rc = &rcs[i];
     // one host thread per member: mirt_render_spp polls its device until the wavefront has drained
-    workers.emplace_back([c, first, mine, rc]() {
+    auto work = [c, first, mine, rc]() {
       *rc = mirt_set_sample_range(c, first);
       if (*rc == MIRT_OK) *rc = mirt_render_spp(c, mine);
-    });
+    };
+    try {
+      workers.emplace_back(work);
+    } catch (...) {  // no thread to be had: this member renders on the calling thread (nothing is thrown across the C ABI)
+      work();
+    }
     first += mine;
   }
   for (std::thread &w : workers) w.join();
@@ -1914,7 +1924,10 @@ int mirt_group_reduce(mirt_group *g) {
     }
     g->tmp_sources = ns;
   }
+  // (an event belongs to the device that is current when it is created and can only be recorded on a stream
+  // of that device: member i's event is made with member i's device current)
   while (g->copied.size() < n - 1) {
+    GROUP_TRY(hipSetDevice(g->members[g->copied.size() + 1]->device));
     hipEvent_t ev;
     GROUP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     g->copied.push_back(ev);
