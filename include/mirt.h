@@ -33,7 +33,9 @@ typedef enum MirtStatus {
   MIRT_ERR_OUT_OF_MEMORY = -3,
   MIRT_ERR_HIP = -4,
   MIRT_ERR_NOT_READY = -5, /* scene or state missing */
-  MIRT_ERR_BAD_SCENE = -6  /* an index in the scene buffers is out of range */
+  MIRT_ERR_BAD_SCENE = -6, /* an index in the scene buffers is out of range */
+  MIRT_ERR_INTERNAL = -7   /* an exception inside the library, caught at the boundary (host memory running out
+                              reads as MIRT_ERR_OUT_OF_MEMORY) */
 } MirtStatus;
 
 /* ------------------------------------------------- scene PODs (bind group 0) */

@@ -123,6 +123,36 @@ int fail(mirt_ctx *c, int status, const std::string &msg) {
   return status;
 }
 
+// No exception crosses the C boundary: every entry point is a function-try-block that ends here.  Host memory
+// running out (std::bad_alloc from a staging vector) reads as MIRT_ERR_OUT_OF_MEMORY, anything else as
+// MIRT_ERR_INTERNAL; the message goes to the context when one can still be written.
+int exception_status(std::string &msg) noexcept {
+  int status = MIRT_ERR_INTERNAL;
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc &) {
+      status = MIRT_ERR_OUT_OF_MEMORY;
+      msg = "out of host memory";
+    } catch (const std::exception &e) {
+      msg = std::string("internal error: ") + e.what();
+    } catch (...) {
+      msg = "internal error";
+    }
+  } catch (...) {  // not even the message could be built
+  }
+  return status;
+}
+int on_exception(mirt_ctx *c) noexcept {
+  std::string msg;
+  const int status = exception_status(msg);
+  try {
+    if (c) c->error = msg;
+  } catch (...) {
+  }
+  return status;
+}
+
 #define HIP_TRY(ctx, expr)                                                                      \
   do {                                                                                          \
     hipError_t _e = (expr);                                                                     \
@@ -553,6 +583,7 @@ const char *mirt_status_string(int status) {
     case MIRT_ERR_HIP: return "HIP runtime error";
     case MIRT_ERR_NOT_READY: return "scene, state or camera not set";
     case MIRT_ERR_BAD_SCENE: return "scene buffers are inconsistent";
+    case MIRT_ERR_INTERNAL: return "internal error";
     default: return "unknown status";
   }
 }
@@ -573,7 +604,7 @@ void mirt_default_params(MirtParams *out) {
   out->stage_kernels = 0;
 }
 
-int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
+int mirt_create(int device_ordinal, mirt_ctx **out_ctx) try {
   if (!out_ctx) return MIRT_ERR_INVALID_ARGUMENT;
   *out_ctx = nullptr;
   int n = 0;
@@ -597,9 +628,11 @@ int mirt_create(int device_ordinal, mirt_ctx **out_ctx) {
   mirt_default_params(&c->params);
   *out_ctx = c;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
-int mirt_destroy(mirt_ctx *ctx) {
+int mirt_destroy(mirt_ctx *ctx) try {
   if (!ctx) return MIRT_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -614,6 +647,8 @@ int mirt_destroy(mirt_ctx *ctx) {
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 // Geometry: the node array (a reserved TLAS block first, then one BLAS block
@@ -938,7 +973,7 @@ static int upload_instances(mirt_ctx *ctx, const MirtSceneDesc *d, DScene &sc) {
   return MIRT_OK;
 }
 
-int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
+int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) try {
   ENTER(ctx);
   if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
   std::string why;
@@ -957,9 +992,11 @@ int mirt_scene_upload(mirt_ctx *ctx, const MirtSceneDesc *d) {
   ctx->have_classic_tables = d->n_classic_refs != 0;
   ctx->have_scene = true;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
+int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) try {
   ENTER(ctx);
   if (!d) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "scene is null");
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
@@ -981,9 +1018,11 @@ int mirt_scene_update_instances(mirt_ctx *ctx, const MirtSceneDesc *d) {
   ctx->have_classic_tables = d->n_classic_refs != 0;
   ctx->have_scene = true;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) {
+int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) try {
   ENTER(ctx);
   if (device_ms) *device_ms = 0.0f;
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
@@ -1033,10 +1072,12 @@ int mirt_scene_update_transforms(mirt_ctx *ctx, const MirtTransform *transforms,
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the host buffers of the copies above must outlive them
   ctx->host_insts.swap(insts);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t threads,
-                      const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) {
+                      const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) try {
   ENTER(ctx);
   if (!width || !height || !threads || !sources || !n_sources || !params)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "state_create: zero size or null pointer");
@@ -1121,9 +1162,11 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   ctx->rng_seeded = false;
   ctx->stamp = 0;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots) {
+int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (ctx->params.rng_mode != MIRT_RNG_PER_SLOT)
@@ -1141,6 +1184,8 @@ int mirt_state_set_rng(mirt_ctx *ctx, const uint32_t (*rng)[4], uint32_t n_slots
   ctx->rng_seeded = true;
   ctx->slots_seeded = false;  // in-flight paths are dropped
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 // The host half of a convergence pass: with `flags` on the device (set there by k_adapt_update, or uploaded here
@@ -1190,48 +1235,58 @@ static int adapt_update_impl(mirt_ctx *ctx, float rel_threshold, uint32_t min_sa
   return install_flags(ctx, nullptr, flags_out, n_active);
 }
 
-int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
+int mirt_adapt_update(mirt_ctx *ctx, float rel_threshold, uint32_t min_samples, uint32_t *n_active) try {
   ENTER(ctx);
   return adapt_update_impl(ctx, rel_threshold, min_samples, n_active, nullptr);
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources) {
+int mirt_read_flags(mirt_ctx *ctx, uint32_t *flags, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (!flags || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_flags: n_sources mismatch");
   HIP_TRY(ctx, hipMemcpyAsync(flags, ctx->st.flags, n_sources * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_read_moments(mirt_ctx *ctx, uint64_t *moments, size_t n_sources) {
+int mirt_read_moments(mirt_ctx *ctx, uint64_t *moments, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state || !ctx->st.moments) return fail(ctx, MIRT_ERR_NOT_READY, "no state with adaptive = 1");
   if (!moments || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_moments: n_sources mismatch");
   HIP_TRY(ctx, hipMemcpyAsync(moments, ctx->st.moments, n_sources * 16, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_write_moments(mirt_ctx *ctx, const uint64_t *moments, size_t n_sources) {
+int mirt_write_moments(mirt_ctx *ctx, const uint64_t *moments, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state || !ctx->st.moments) return fail(ctx, MIRT_ERR_NOT_READY, "no state with adaptive = 1");
   if (!moments || n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "write_moments: n_sources mismatch");
   HIP_TRY(ctx, hipMemcpyAsync(ctx->st.moments, moments, n_sources * 16, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_camera_set(mirt_ctx *ctx, const MirtCamera *camera) {
+int mirt_camera_set(mirt_ctx *ctx, const MirtCamera *camera) try {
   ENTER(ctx);
   if (!camera) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "camera is null");
   ctx->camera = *camera;
   ctx->have_camera = true;
   if (camera->changed != 0 && ctx->have_state) return mirt_reset_accum(ctx);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_reset_accum(mirt_ctx *ctx) {
+int mirt_reset_accum(mirt_ctx *ctx) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   // sampleCleanup (shaders/sample.slang:123-145) for every source, including
@@ -1246,13 +1301,17 @@ int mirt_reset_accum(mirt_ctx *ctx) {
   ctx->next_sample = 0;
   ctx->slots_seeded = false;  // in-flight paths are dropped
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_set_sample_range(mirt_ctx *ctx, uint32_t first_sample) {
+int mirt_set_sample_range(mirt_ctx *ctx, uint32_t first_sample) try {
   ENTER(ctx);
   ctx->next_sample = first_sample;
   ctx->slots_seeded = false;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 static int check_ready(mirt_ctx *ctx) {
@@ -1266,7 +1325,7 @@ static int check_ready(mirt_ctx *ctx) {
   return MIRT_OK;
 }
 
-int mirt_step(mirt_ctx *ctx, uint32_t n_frames) {
+int mirt_step(mirt_ctx *ctx, uint32_t n_frames) try {
   ENTER(ctx);
   int rc = check_ready(ctx);
   if (rc != MIRT_OK) return rc;
@@ -1275,9 +1334,11 @@ int mirt_step(mirt_ctx *ctx, uint32_t n_frames) {
   // samples keep regenerating: no limit on the number handed out
   for (uint32_t f = 0; f < n_frames; ++f) run_frame(ctx, ~0ull, ctx->next_sample, false);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
+int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) try {
   ENTER(ctx);
   int rc = check_ready(ctx);
   if (rc != MIRT_OK) return rc;
@@ -1310,16 +1371,20 @@ int mirt_render_spp(mirt_ctx *ctx, uint32_t spp) {
   ctx->next_sample = first + spp;
   ctx->slots_seeded = false;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_synchronize(mirt_ctx *ctx) {
+int mirt_synchronize(mirt_ctx *ctx) try {
   ENTER(ctx);
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev_collect(ctx);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels) {
+int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (!rgb || n_pixels != (size_t)ctx->st.width * ctx->st.height)
@@ -1329,9 +1394,11 @@ int mirt_read_output(mirt_ctx *ctx, uint32_t *rgb, size_t n_pixels) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev_collect(ctx);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count, size_t n_sources) {
+int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "read_accum: n_sources mismatch");
@@ -1345,9 +1412,11 @@ int mirt_read_accum(mirt_ctx *ctx, uint32_t *sum4, uint32_t *count, size_t n_sou
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ev_collect(ctx);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count, size_t n_sources) {
+int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "copy_accum: n_sources mismatch");
@@ -1358,9 +1427,11 @@ int mirt_copy_accum_to_device(mirt_ctx *ctx, void *dev_sum4, void *dev_count, si
   if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(dev_count, ctx->st.count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4, const void *dev_count, size_t n_sources) {
+int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4, const void *dev_count, size_t n_sources) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (n_sources != ctx->st.n_sources) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "load_accum: n_sources mismatch");
@@ -1371,6 +1442,8 @@ int mirt_load_accum_from_device(mirt_ctx *ctx, const void *dev_sum4, const void 
   if (dev_count) HIP_TRY(ctx, hipMemcpyAsync(ctx->st.count, dev_count, n_sources * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, size_t n, MirtHitId *out,
@@ -1439,13 +1512,15 @@ static int trace_common(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, s
   return MIRT_OK;
 }
 
-int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out, MirtTraversalCounts *counts) {
+int mirt_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out, MirtTraversalCounts *counts) try {
   ENTER(ctx);
   return trace_common(ctx, rays, nullptr, n, out, counts, false, 0, nullptr);
+} catch (...) {
+  return on_exception(ctx);
 }
 
 int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n, MirtHitId *out,
-                              MirtTraversalCounts *counts) {
+                              MirtTraversalCounts *counts) try {
   ENTER(ctx);
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
   if (n == 0) return MIRT_OK;
@@ -1483,21 +1558,27 @@ int mirt_trace_closest_static(mirt_ctx *ctx, const MirtRay *rays, size_t n, Mirt
     counts->blas_nodes = h[3]; counts->triangles = h[4];
   }
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 int mirt_trace_any(mirt_ctx *ctx, const MirtRay *rays, const float *tmax, size_t n, MirtHitId *out,
-                   MirtTraversalCounts *counts) {
+                   MirtTraversalCounts *counts) try {
   ENTER(ctx);
   return trace_common(ctx, rays, tmax, n, out, counts, true, 0, nullptr);
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, uint32_t repeats, double *ms_per_launch) {
+int mirt_bench_trace_closest(mirt_ctx *ctx, const MirtRay *rays, size_t n, uint32_t repeats, double *ms_per_launch) try {
   ENTER(ctx);
   if (!ms_per_launch || repeats == 0) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bench_trace: bad arguments");
   return trace_common(ctx, rays, nullptr, n, nullptr, nullptr, false, repeats, ms_per_launch);
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_bench_gather(mirt_ctx *ctx, size_t table_bytes, uint32_t steps, uint32_t repeats, double *lane_steps_per_s) {
+int mirt_bench_gather(mirt_ctx *ctx, size_t table_bytes, uint32_t steps, uint32_t repeats, double *lane_steps_per_s) try {
   ENTER(ctx);
   if (!lane_steps_per_s) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "bench_gather: null pointer");
   if (table_bytes == 0) {
@@ -1509,17 +1590,21 @@ int mirt_bench_gather(mirt_ctx *ctx, size_t table_bytes, uint32_t steps, uint32_
   const int rc = gather_ceiling(ctx->stream, ctx->num_cus, table_bytes, steps, repeats, lane_steps_per_s, err);
   if (rc != MIRT_OK) return fail(ctx, rc, err);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_scene_bytes(mirt_ctx *ctx, uint64_t *node_and_triangle_bytes, uint64_t *leaf_cache_bytes) {
+int mirt_scene_bytes(mirt_ctx *ctx, uint64_t *node_and_triangle_bytes, uint64_t *leaf_cache_bytes) try {
   ENTER(ctx);
   if (!ctx->have_scene) return fail(ctx, MIRT_ERR_NOT_READY, "no scene uploaded");
   if (node_and_triangle_bytes) *node_and_triangle_bytes = ctx->sc.geo_bytes;
   if (leaf_cache_bytes) *leaf_cache_bytes = ctx->sc.leaf_cache_bytes;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
+int mirt_stats(mirt_ctx *ctx, MirtStats *out) try {
   ENTER(ctx);
   if (!out) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "stats: null pointer");
   memset(out, 0, sizeof(*out));
@@ -1560,9 +1645,11 @@ int mirt_stats(mirt_ctx *ctx, MirtStats *out) {
   out->shade_launches = ctx->kernel_launches[K_SHADE];     out->shade_ms = ctx->kernel_ms[K_SHADE];
   out->sample_launches = ctx->kernel_launches[K_SAMPLE];   out->sample_ms = ctx->kernel_ms[K_SAMPLE];
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_stats_reset(mirt_ctx *ctx) {
+int mirt_stats_reset(mirt_ctx *ctx) try {
   ENTER(ctx);
   if (ctx->have_state) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1572,21 +1659,27 @@ int mirt_stats_reset(mirt_ctx *ctx) {
   for (int k = 0; k < K_KINDS; ++k) { ctx->kernel_ms[k] = 0.0; ctx->kernel_launches[k] = 0; }
   ctx->frames_total = 0;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_set_counting(mirt_ctx *ctx, int enabled) {
+int mirt_set_counting(mirt_ctx *ctx, int enabled) try {
   ENTER(ctx);
   ctx->counting = enabled != 0;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_set_event_timing(mirt_ctx *ctx, int enabled) {
+int mirt_set_event_timing(mirt_ctx *ctx, int enabled) try {
   ENTER(ctx);
   ctx->event_timing = enabled != 0;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_t *n_written) {
+int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_t *n_written) try {
   ENTER(ctx);
   if (!ctx->have_state) return fail(ctx, MIRT_ERR_NOT_READY, "no state");
   if (!out || !n_written) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "dump: null pointer");
@@ -1606,9 +1699,11 @@ int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_
   for (uint32_t k = 0; k < cnt && w < capacity; ++k) out[w++] = all[idx[k]];
   *n_written = w;
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const float *c, size_t n, float *out6) {
+int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const float *c, size_t n, float *out6) try {
   ENTER(ctx);
   if (!a || !b || !c || !out6) return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "selftest: null pointer");
   if (n == 0) return MIRT_OK;
@@ -1631,6 +1726,8 @@ int mirt_math_selftest(mirt_ctx *ctx, const float *a, const float *b, const floa
   free_all(tmp);
   if (e != hipSuccess) return fail(ctx, MIRT_ERR_HIP, hipGetErrorString(e));
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 // ------------------------------------------------------------------ groups
@@ -1653,6 +1750,16 @@ namespace {
 
 int gfail(mirt_group *g, int status, const std::string &msg) {
   if (g) g->error = msg;
+  return status;
+}
+
+int on_group_exception(mirt_group *g) noexcept {
+  std::string msg;
+  const int status = exception_status(msg);
+  try {
+    if (g) g->error = msg;
+  } catch (...) {
+  }
   return status;
 }
 
@@ -1686,7 +1793,7 @@ void group_free_staging(mirt_group *g) {
 extern "C" {
 
 int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions, uint32_t *faces4, uint32_t n_faces,
-                    MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes, float *device_ms) {
+                    MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes, float *device_ms) try {
   ENTER(ctx);
   if (!n_nodes || !nodes || nodes_capacity == 0 || (n_faces != 0 && (!faces4 || !positions4)))
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_blas: null argument");
@@ -1707,11 +1814,13 @@ int mirt_build_blas(mirt_ctx *ctx, const float *positions4, uint32_t n_positions
                                    device_ms, &ctx->build_ws, &ctx->build_ws_bytes, err);
   if (rc != MIRT_OK) return fail(ctx, rc, err);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
 int mirt_build_tlas(mirt_ctx *ctx, const float *geom_aabbs6, uint32_t n_geometries, const MirtTransform *transforms,
                     uint32_t n_transforms, const MirtInstance *instances, uint32_t n_instances, MirtBVHNode *nodes,
-                    uint32_t nodes_capacity, uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms) {
+                    uint32_t nodes_capacity, uint32_t *n_nodes, uint32_t *instance_ids, float *device_ms) try {
   ENTER(ctx);
   if (!geom_aabbs6 || !transforms || !instances || !nodes || !n_nodes || !instance_ids || n_instances == 0 || nodes_capacity == 0)
     return fail(ctx, MIRT_ERR_INVALID_ARGUMENT, "build_tlas: null argument or no instances");
@@ -1739,9 +1848,11 @@ int mirt_build_tlas(mirt_ctx *ctx, const float *geom_aabbs6, uint32_t n_geometri
                                    nodes_capacity, n_nodes, instance_ids, device_ms, &ctx->build_ws, &ctx->build_ws_bytes, err);
   if (rc != MIRT_OK) return fail(ctx, rc, err);
   return MIRT_OK;
+} catch (...) {
+  return on_exception(ctx);
 }
 
-int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group) {
+int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group) try {
   if (!device_ordinals || n < 1 || !out_group) return MIRT_ERR_INVALID_ARGUMENT;
   *out_group = nullptr;
   mirt_group *g = new (std::nothrow) mirt_group;
@@ -1773,15 +1884,19 @@ int mirt_group_create(const int *device_ordinals, int n, mirt_group **out_group)
   (void)hipGetLastError();
   *out_group = g;
   return MIRT_OK;
+} catch (...) {
+  return on_group_exception(nullptr);
 }
 
-int mirt_group_destroy(mirt_group *g) {
+int mirt_group_destroy(mirt_group *g) try {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   group_free_staging(g);
   for (hipEvent_t ev : g->copied) (void)hipEventDestroy(ev);
   for (mirt_ctx *m : g->members) (void)mirt_destroy(m);
   delete g;
   return MIRT_OK;
+} catch (...) {
+  return on_group_exception(g);
 }
 
 int mirt_group_size(const mirt_group *g) { return g ? (int)g->members.size() : 0; }
@@ -1792,15 +1907,19 @@ mirt_ctx *mirt_group_member(mirt_group *g, int i) {
 
 const char *mirt_group_last_error(const mirt_group *g) { return g ? g->error.c_str() : "null group"; }
 
-int mirt_group_scene_upload(mirt_group *g, const MirtSceneDesc *scene) {
+int mirt_group_scene_upload(mirt_group *g, const MirtSceneDesc *scene) try {
   return for_members(g, "scene_upload", [&](mirt_ctx *c) { return mirt_scene_upload(c, scene); });
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_scene_update_instances(mirt_group *g, const MirtSceneDesc *scene) {
+int mirt_group_scene_update_instances(mirt_group *g, const MirtSceneDesc *scene) try {
   return for_members(g, "scene_update_instances", [&](mirt_ctx *c) { return mirt_scene_update_instances(c, scene); });
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_scene_update_transforms(mirt_group *g, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) {
+int mirt_group_scene_update_transforms(mirt_group *g, const MirtTransform *transforms, uint32_t n_transforms, float *device_ms) try {
   float worst = 0.0f;
   const int rc = for_members(g, "scene_update_transforms", [&](mirt_ctx *c) {
     float ms = 0.0f;
@@ -1810,30 +1929,38 @@ int mirt_group_scene_update_transforms(mirt_group *g, const MirtTransform *trans
   });
   if (device_ms) *device_ms = worst;
   return rc;
+} catch (...) {
+  return on_group_exception(g);
 }
 
 int mirt_group_state_create(mirt_group *g, uint32_t width, uint32_t height, uint32_t threads,
-                            const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) {
+                            const MirtSampleSource *sources, uint32_t n_sources, const MirtParams *params) try {
   const int rc = for_members(g, "state_create", [&](mirt_ctx *c) {
     return mirt_state_create(c, width, height, threads, sources, n_sources, params);
   });
   if (rc == MIRT_OK) g->next_sample = 0;
   return rc;
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_camera_set(mirt_group *g, const MirtCamera *camera) {
+int mirt_group_camera_set(mirt_group *g, const MirtCamera *camera) try {
   const int rc = for_members(g, "camera_set", [&](mirt_ctx *c) { return mirt_camera_set(c, camera); });
   if (rc == MIRT_OK && camera && camera->changed != 0) g->next_sample = 0;  // the members cleared their accumulators
   return rc;
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_reset_accum(mirt_group *g) {
+int mirt_group_reset_accum(mirt_group *g) try {
   const int rc = for_members(g, "reset_accum", [&](mirt_ctx *c) { return mirt_reset_accum(c); });
   if (rc == MIRT_OK) g->next_sample = 0;
   return rc;
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_render_spp(mirt_group *g, uint32_t spp) {
+int mirt_group_render_spp(mirt_group *g, uint32_t spp) try {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   const size_t n = g->members.size();
   std::vector<int> rcs(n, MIRT_OK);
@@ -1862,9 +1989,11 @@ int mirt_group_render_spp(mirt_group *g, uint32_t spp) {
       return gfail(g, rcs[i], "render_spp: member " + std::to_string(i) + ": " + mirt_last_error(g->members[i]));
   g->next_sample = first;
   return MIRT_OK;
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_adapt_update(mirt_group *g, float rel_threshold, uint32_t min_samples, uint32_t *n_active) {
+int mirt_group_adapt_update(mirt_group *g, float rel_threshold, uint32_t min_samples, uint32_t *n_active) try {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   // the totals — sums, counts, moments of every member — on member 0, which decides; the others take its flags
   int rc = mirt_group_reduce(g);
@@ -1884,9 +2013,11 @@ int mirt_group_adapt_update(mirt_group *g, float rel_threshold, uint32_t min_sam
   }
   if (n_active) *n_active = left;
   return MIRT_OK;
+} catch (...) {
+  return on_group_exception(g);
 }
 
-int mirt_group_reduce(mirt_group *g) {
+int mirt_group_reduce(mirt_group *g) try {
   if (!g) return MIRT_ERR_INVALID_ARGUMENT;
   mirt_ctx *root = g->members[0];
   if (!root->have_state) return gfail(g, MIRT_ERR_NOT_READY, "reduce: no state");
@@ -1963,6 +2094,8 @@ int mirt_group_reduce(mirt_group *g) {
   }
 #undef GROUP_TRY
   return MIRT_OK;
+} catch (...) {
+  return on_group_exception(g);
 }
 
 }  // extern "C"

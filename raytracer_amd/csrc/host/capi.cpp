@@ -22,6 +22,26 @@ struct mirth_scene {
 
 namespace {
 
+// No exception crosses the C boundary: every entry point that returns a status is a function-try-block that
+// ends here, with -1 and a message in the scene's error string when one can still be written.
+int on_exception(mirth_scene *s) noexcept {
+  try {
+    std::string msg;
+    try {
+      throw;
+    } catch (const std::bad_alloc &) {
+      msg = "out of host memory";
+    } catch (const std::exception &e) {
+      msg = std::string("internal error: ") + e.what();
+    } catch (...) {
+      msg = "internal error";
+    }
+    if (s) s->error = msg;
+  } catch (...) {
+  }
+  return -1;
+}
+
 const char kMagic[8] = {'M', 'I', 'R', 'T', 'M', 'E', 'S', 'H'};
 
 // the id add_mesh returned, or -1 with the message of a failed builder callback
@@ -134,7 +154,7 @@ mirth_scene *mirth_scene_new(void) { return new (std::nothrow) mirth_scene(); }
 void mirth_scene_free(mirth_scene *s) { delete s; }
 const char *mirth_last_error(const mirth_scene *s) { return s ? s->error.c_str() : "null scene"; }
 
-int mirth_load_mesh_obj(mirth_scene *s, const char *path) {
+int mirth_load_mesh_obj(mirth_scene *s, const char *path) try {
   if (!s || !path) return -1;
   std::string key = std::string("TOBJ:") + path;
   auto it = s->scene.by_desc.find(key);
@@ -142,14 +162,24 @@ int mirth_load_mesh_obj(mirth_scene *s, const char *path) {
   ObjModel m;
   if (!load_obj_first_model(path, m, s->error)) return -1;
   return added(s, s->scene.add_mesh(key, Mesh::from_model(m)));
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_load_mesh_rect(mirth_scene *s) { return s ? added(s, s->scene.add_mesh("Rect", Mesh::rect())) : -1; }
-int mirth_load_mesh_cube(mirth_scene *s) { return s ? added(s, s->scene.add_mesh("Cube", Mesh::cube())) : -1; }
+int mirth_load_mesh_rect(mirth_scene *s) try {
+  return s ? added(s, s->scene.add_mesh("Rect", Mesh::rect())) : -1;
+} catch (...) {
+  return on_exception(s);
+}
+int mirth_load_mesh_cube(mirth_scene *s) try {
+  return s ? added(s, s->scene.add_mesh("Cube", Mesh::cube())) : -1;
+} catch (...) {
+  return on_exception(s);
+}
 
 int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positions, uint32_t n_positions,
                           const float *normals, uint32_t n_normals, const uint32_t *indices,
-                          uint32_t n_indices) {
+                          uint32_t n_indices) try {
   if (!s || !name || !positions || !indices) return -1;
   ObjModel m;
   m.positions.assign(positions, positions + n_positions);
@@ -157,9 +187,11 @@ int mirth_load_mesh_model(mirth_scene *s, const char *name, const float *positio
   m.indices.assign(indices, indices + n_indices);
   if (!validate_model(m, s->error)) return -1;
   return added(s, s->scene.add_mesh(std::string("MODEL:") + name, Mesh::from_model(m)));
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_load_mesh_model_file(mirth_scene *s, const char *path) {
+int mirth_load_mesh_model_file(mirth_scene *s, const char *path) try {
   if (!s || !path) return -1;
   std::string key = std::string("MODELFILE:") + path;
   auto it = s->scene.by_desc.find(key);
@@ -167,17 +199,21 @@ int mirth_load_mesh_model_file(mirth_scene *s, const char *path) {
   ObjModel m;
   if (!read_model_file(path, m, s->error) || !validate_model(m, s->error)) return -1;
   return added(s, s->scene.add_mesh(key, Mesh::from_model(m)));
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed) {
+int mirth_load_mesh_knot(mirth_scene *s, uint32_t n_u, uint32_t n_v, uint32_t seed) try {
   if (!s || n_u < 3 || n_v < 3) return -1;
   std::string key = "KNOT:" + std::to_string(n_u) + "x" + std::to_string(n_v) + ":" + std::to_string(seed);
   auto it = s->scene.by_desc.find(key);
   if (it != s->scene.by_desc.end()) return (int)it->second;
   return added(s, s->scene.add_mesh(key, Mesh::from_model(make_knot_model(n_u, n_v, seed))));
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels, uint32_t seed) {
+int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char *name, uint32_t levels, uint32_t seed) try {
   if (!s || !asset_dir || !name || levels > 8) return -1;
   const std::string dir = asset_dir;
   std::string key = std::string("SUBDIV:") + dir + "/" + name + ":" + std::to_string(levels) + ":" + std::to_string(seed);
@@ -199,6 +235,8 @@ int mirth_load_mesh_subdivided(mirth_scene *s, const char *asset_dir, const char
     return -1;
   }
   return added(s, s->scene.add_mesh(key, Mesh::from_model(subdivide_model(base, levels, seed))));
+} catch (...) {
+  return on_exception(s);
 }
 
 void mirth_det_sincos(double x, double *s_out, double *c_out) {
@@ -206,14 +244,16 @@ void mirth_det_sincos(double x, double *s_out, double *c_out) {
   if (c_out) *c_out = host_det_cos(x);
 }
 
-int mirth_set_dragon_standin(mirth_scene *s, int kind, uint32_t levels) {
+int mirth_set_dragon_standin(mirth_scene *s, int kind, uint32_t levels) try {
   if (!s || kind < 0 || kind > 1 || levels > 8) return -1;
   s->standin_kind = kind;
   s->standin_levels = levels;
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter) {
+int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uint32_t *rgba8, uint32_t filter) try {
   if (!s || !rgba8 || width == 0 || height == 0 || width > 65536u || height > 65536u || filter > MIRT_FILTER_BILINEAR)
     return -1;
   if (s->scene.texels.size() + (size_t)width * height > 0xFFFFFFFFull) return -1;
@@ -222,17 +262,21 @@ int mirth_add_texture(mirth_scene *s, uint32_t width, uint32_t height, const uin
   s->scene.textures.push_back(t);
   s->bound = false;
   return (int)s->scene.textures.size();  // 1-based: 0 means "no texture" in a material
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_add_texture_png(mirth_scene *s, const void *png, size_t len, uint32_t filter) {
+int mirth_add_texture_png(mirth_scene *s, const void *png, size_t len, uint32_t filter) try {
   if (!s || !png || filter > MIRT_FILTER_BILINEAR) return -1;
   uint32_t w = 0, h = 0;
   std::vector<uint32_t> texels;
   if (!decode_png_rgba8(static_cast<const unsigned char *>(png), len, w, h, texels, s->error)) return -1;
   return mirth_add_texture(s, w, h, texels.data(), filter);
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info) {
+int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info) try {
   if (!s || !path) return -1;
   MirthGltfInfo local;
   memset(&local, 0, sizeof(local));
@@ -240,9 +284,11 @@ int mirth_load_gltf(mirth_scene *s, const char *path, MirthGltfInfo *info) {
   s->bound = false;
   if (info) *info = local;
   return (int)local.n_instances;
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v, float scale, float offset) {
+int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v, float scale, float offset) try {
   if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size() || axis_u < 0 || axis_u > 2 || axis_v < 0 || axis_v > 2)
     return -1;
   MeshData &d = s->scene.meshes[(size_t)mesh_id];
@@ -254,11 +300,15 @@ int mirth_mesh_set_planar_uv(mirth_scene *s, int mesh_id, int axis_u, int axis_v
   }
   s->bound = false;
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_add_material(mirth_scene *s, const MirtMaterial *m) {
+int mirth_add_material(mirth_scene *s, const MirtMaterial *m) try {
   if (!s || !m) return -1;
   return (int)s->scene.add_material(*m);
+} catch (...) {
+  return on_exception(s);
 }
 void mirth_default_material(MirtMaterial *out) {
   if (out) *out = default_material();
@@ -267,7 +317,7 @@ void mirth_default_camera(MirtCamera *out) {
   if (out) *out = default_camera();
 }
 
-int mirth_spawn(mirth_scene *s, const MirtTransform *t, int mesh_id, int material_id) {
+int mirth_spawn(mirth_scene *s, const MirtTransform *t, int mesh_id, int material_id) try {
   if (!s || !t || mesh_id < 0 || material_id < 0) return -1;
   if ((size_t)mesh_id >= s->scene.meshes.size() || (size_t)material_id >= s->scene.material_server.size()) {
     s->error = "spawn: unknown mesh or material id";
@@ -275,9 +325,11 @@ int mirth_spawn(mirth_scene *s, const MirtTransform *t, int mesh_id, int materia
   }
   s->bound = false;
   return (int)s->scene.spawn(*t, (uint32_t)mesh_id, (uint32_t)material_id);
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3], int with_ceiling_light) {
+int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3], int with_ceiling_light) try {
   if (!s || !dims || !pos) return -1;
   s->bound = false;
   spawn_cornell(s->scene, {dims[0], dims[1], dims[2]}, {pos[0], pos[1], pos[2]}, with_ceiling_light != 0);
@@ -286,10 +338,12 @@ int mirth_spawn_cornell(mirth_scene *s, const float dims[3], const float pos[3],
     return -1;
   }
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
 int mirth_build_blas_host(const float *positions4, uint32_t n_positions, uint32_t *faces4, uint32_t n_faces,
-                          MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes) {
+                          MirtBVHNode *nodes, uint32_t nodes_capacity, uint32_t *n_nodes) try {
   if (!n_nodes || !nodes || (n_faces != 0 && (!positions4 || !faces4))) return -1;
   for (size_t k = 0; k < (size_t)n_faces * 4; ++k)
     if (faces4[k] >= n_positions) return -1;
@@ -304,17 +358,21 @@ int mirth_build_blas_host(const float *positions4, uint32_t n_positions, uint32_
   for (size_t i = 0; i < blas.nodes.size(); ++i) nodes[i] = to_gpu(blas.nodes[i]);
   if (n_faces) memcpy(faces4, blas.mesh.faces.data(), (size_t)n_faces * 16);
   return 0;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
-int mirth_set_blas_builder(mirth_scene *s, mirth_blas_builder_fn fn, void *user) {
+int mirth_set_blas_builder(mirth_scene *s, mirth_blas_builder_fn fn, void *user) try {
   if (!s) return -1;
   s->scene.blas_builder = fn;
   s->scene.blas_builder_user = user;
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
 int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32_t dragon_n_u,
-                       uint32_t dragon_n_v, MirthConfigInfo *info) {
+                       uint32_t dragon_n_v, MirthConfigInfo *info) try {
   if (!s || !info || config < 1 || config > 5) return -1;
   const std::string dir = asset_dir ? asset_dir : ".";
   if (dragon_n_u == 0) dragon_n_u = 2722;  // 2 * 2722 * 160 = 871 040 triangles
@@ -456,9 +514,11 @@ int mirth_build_config(mirth_scene *s, int config, const char *asset_dir, uint32
     return -1;
   }
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_bind(mirth_scene *s) {
+int mirth_bind(mirth_scene *s) try {
   if (!s) return -1;
   s->scene.bind();
   s->bound = true;
@@ -467,32 +527,40 @@ int mirth_bind(mirth_scene *s) {
     return -1;
   }
   return 0;
+} catch (...) {
+  return on_exception(s);
 }
 
-int mirth_scene_desc(const mirth_scene *s, MirtSceneDesc *out) {
+int mirth_scene_desc(const mirth_scene *s, MirtSceneDesc *out) try {
   if (!s || !out || !s->bound) return -1;
   s->scene.fill_desc(*out);
   return 0;
+} catch (...) {
+  return on_exception(const_cast<mirth_scene *>(s));
 }
 
 int mirth_make_sample_sources(uint32_t width, uint32_t height, uint64_t seed, int shuffle,
-                              MirtSampleSource *out) {
+                              MirtSampleSource *out) try {
   if (!out || width == 0 || height == 0) return -1;
   std::vector<MirtSampleSource> v = make_sample_sources(width, height, seed, shuffle);
   memcpy(out, v.data(), v.size() * sizeof(MirtSampleSource));
   return 0;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
-int mirth_obj_to_model_file(const char *obj_path, const char *out_path) {
+int mirth_obj_to_model_file(const char *obj_path, const char *out_path) try {
   if (!obj_path || !out_path) return -1;
   ObjModel m;
   std::string err;
   if (!load_obj_first_model(obj_path, m, err)) return -1;
   return write_model_file(out_path, m, err) ? 0 : -1;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
 int mirth_parse_obj_counts(const char *text, size_t len, uint32_t *n_positions, uint32_t *n_normals,
-                           uint32_t *n_triangles) {
+                           uint32_t *n_triangles) try {
   if (!text) return -1;
   ObjModel m;
   std::string err;
@@ -501,20 +569,24 @@ int mirth_parse_obj_counts(const char *text, size_t len, uint32_t *n_positions, 
   if (n_normals) *n_normals = (uint32_t)m.normals.size() / 3;
   if (n_triangles) *n_triangles = (uint32_t)m.indices.size() / 3;
   return 0;
+} catch (...) {
+  return on_exception(nullptr);
 }
 
 int mirth_mesh_counts(const mirth_scene *s, int mesh_id, uint32_t *n_vertices, uint32_t *n_faces,
-                      uint32_t *n_nodes) {
+                      uint32_t *n_nodes) try {
   if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size()) return -1;
   const MeshData &d = s->scene.meshes[mesh_id];
   if (n_vertices) *n_vertices = (uint32_t)d.mesh.positions.size();
   if (n_faces) *n_faces = (uint32_t)d.mesh.n_faces();
   if (n_nodes) *n_nodes = (uint32_t)d.nodes.size();
   return 0;
+} catch (...) {
+  return on_exception(const_cast<mirth_scene *>(s));
 }
 
 int mirth_mesh_copy(const mirth_scene *s, int mesh_id, float *positions4, float *normals4, uint32_t *faces4,
-                    MirtBVHNode *nodes) {
+                    MirtBVHNode *nodes) try {
   if (!s || mesh_id < 0 || (size_t)mesh_id >= s->scene.meshes.size()) return -1;
   const MeshData &d = s->scene.meshes[mesh_id];
   if (positions4) memcpy(positions4, d.mesh.positions.data(), d.mesh.positions.size() * 16);
@@ -522,6 +594,8 @@ int mirth_mesh_copy(const mirth_scene *s, int mesh_id, float *positions4, float 
   if (faces4) memcpy(faces4, d.mesh.faces.data(), d.mesh.faces.size() * 4);
   if (nodes) memcpy(nodes, d.nodes.data(), d.nodes.size() * sizeof(MirtBVHNode));
   return 0;
+} catch (...) {
+  return on_exception(const_cast<mirth_scene *>(s));
 }
 
 }  // extern "C"

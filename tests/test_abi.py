@@ -86,6 +86,22 @@ def test_status_strings_and_default_params_need_no_device():
     assert np.float32(p.exposure) == np.exp2(np.float32(-2.5))
 
 
+def test_no_exception_leaves_the_host_library():
+    """A request the host cannot allocate (a knot mesh of 2^40 vertices) comes back as a status and a
+    message — every entry point of both libraries is a function-try-block, nothing is thrown across the C
+    boundary (the caller is C, Rust or ctypes) — and the scene object stays usable."""
+    H = ffi.host_lib()
+    s = H.mirth_scene_new()
+    try:
+        assert H.mirth_load_mesh_knot(s, 1 << 20, 1 << 20, 1) == -1
+        H.mirth_last_error.restype = C.c_char_p
+        assert H.mirth_last_error(s) in (b"out of host memory",) or H.mirth_last_error(s).startswith(b"internal error")
+        assert H.mirth_load_mesh_knot(s, 64, 8, 1) >= 0
+    finally:
+        H.mirth_scene_free(s)
+    assert ffi.device_lib().mirt_status_string(-7) == b"internal error"
+
+
 def test_two_rank_gloo_reduce_of_partial_accumulators():
     """Samples-per-pixel are partitioned over ranks, each rank accumulates its share,
     and one integer all-reduce combines them: bit-identical to a single-rank render.
