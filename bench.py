@@ -652,7 +652,7 @@ def main():
         dist.destroy_process_group()
     pt.close()
     if rank == 0:
-        # the second stand-in geometry, after this context has released its 12 GB of path state
+        # the second stand-in geometry, after this context has released its gigabytes of path state
         if (world == 1 and args.config == 3 and args.geometry == "knot" and args.mode == "render"
                 and not args.no_secondary and args.width == 0 and args.height == 0):
             out["secondary"] = secondary_line(args, device_of(local_rank))

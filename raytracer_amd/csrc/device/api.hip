@@ -1101,9 +1101,16 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if ((rc = dev_alloc(ctx, own, &st.ray, threads)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.hit, threads)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.path, threads)) != MIRT_OK) return rc;
-  if ((rc = dev_alloc(ctx, own, &st.shadow, threads)) != MIRT_OK) return rc;
-  for (int q = 0; q < Q_COUNT; ++q)
-    if ((rc = dev_alloc(ctx, own, &st.qdata[q], threads)) != MIRT_OK) return rc;
+  // what only some shading paths touch is only allocated for them (52 of a slot's 184 bytes): the connect
+  // stage's records and queue with per-material shading and light sampling, the four material queues with one
+  // kernel per material on top of that
+  const bool connect_stage = params->shade_mode == MIRT_SHADE_CLASSIC && params->nee != 0u;
+  const bool material_queues = connect_stage && params->stage_kernels != 0u;
+  if ((rc = dev_alloc(ctx, own, &st.shadow, connect_stage ? threads : 0u)) != MIRT_OK) return rc;
+  for (int q = 0; q < Q_COUNT; ++q) {
+    const bool used = q < Q_CONNECT || (q == Q_CONNECT ? connect_stage : material_queues);
+    if ((rc = dev_alloc(ctx, own, &st.qdata[q], used ? threads : 0u)) != MIRT_OK) return rc;
+  }
   if ((rc = dev_alloc(ctx, own, &st.qcount, QW_COUNT)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.stats, S_COUNT)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.sample_index, 1)) != MIRT_OK) return rc;
