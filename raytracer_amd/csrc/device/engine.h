@@ -146,6 +146,19 @@ struct RayIn {
 #define MIRT_WORK_CHUNK 128u
 #endif
 constexpr uint32_t kChunk = MIRT_WORK_CHUNK;
+// Launches with fewer entries than one chunk per wave of the grid (the per-frame call at 512 x 512 hands every
+// lane of the GPU one ray) last as long as their slowest wave: smaller chunks, taken while fewer than 24 lanes
+// walk, leave a wave that is stuck with long rays alone and give the others more to do (k_extend per frame at
+// 512 x 512, chunk / threshold: 64 / 56 1.050 ms, 64 / 1 1.024, 64 / 16 1.029, 32 / 24 1.022, 32 / 8 1.056,
+// 32 / 1 1.263, 16 / 1 1.60).
+#ifndef MIRT_SMALL_CHUNK
+#define MIRT_SMALL_CHUNK 32u
+#endif
+#ifndef MIRT_SMALL_REFILL_BELOW
+#define MIRT_SMALL_REFILL_BELOW 24
+#endif
+constexpr uint32_t kSmallChunk = MIRT_SMALL_CHUNK;
+constexpr int kSmallRefillBelow = MIRT_SMALL_REFILL_BELOW;
 #ifndef MIRT_LONE_LEAF
 #define MIRT_LONE_LEAF 1
 #endif
@@ -301,10 +314,10 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   const BufferRsrc geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(sc.geo), 0, (int)sc.geo_bytes, 0x00020000);
   const uint32_t tlas_nbase = sc.tlas_base * 32u;
 
-  // wave-uniform work cursor.  A launch with fewer than kChunk entries per wave of the grid hands out chunks
-  // of 64: with 128 only half of the waves would find work, each with two rays for every lane, and a launch
-  // that small lasts as long as its slowest wave (the per-frame call at 512 x 512: 1.27 -> 1.10 ms).
-  const uint32_t chunk = ws.count >= kChunk * (kEngineBlock / 64u) * gridDim.x ? kChunk : (kChunk < 64u ? kChunk : 64u);
+  // wave-uniform work cursor; small launches take smaller chunks and refill later (kSmallChunk above)
+  const bool small_launch = ws.count < kChunk * (kEngineBlock / 64u) * gridDim.x;
+  const uint32_t chunk = !small_launch ? kChunk : (kChunk < kSmallChunk ? kChunk : kSmallChunk);
+  const int refill_below = small_launch ? kSmallRefillBelow : kRefillBelow;
   uint32_t chunk_next = 0, chunk_end = 0;
   bool exhausted = false;
 
@@ -343,7 +356,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
     const int n_walking = __popcll(__ballot((fl & F_WALK) != 0u));
     const int n_held = __popcll(__ballot((fl & (F_WALK | F_HOLD)) == (F_WALK | F_HOLD)));
     if ((n_held != 0 && kServiceFrac * n_held >= n_walking) || n_held == n_walking ||
-        (!exhausted && n_walking < kRefillBelow)) {
+        (!exhausted && n_walking < refill_below)) {
       MIRT_PH_COUNT(0);
 #ifdef MIRT_PHASE_TIMING
       const unsigned long long ph_sp0 = MIRT_PH_NOW();
@@ -708,7 +721,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
           finish(fin, payload, (fl & F_FOUND) != 0u, t, best);
         }
         if ((fl & F_WALK) == 0u) fl = 0u;
-        if (!exhausted && __popcll(__ballot((fl & F_WALK) != 0u)) < kRefillBelow) {
+        if (!exhausted && __popcll(__ballot((fl & F_WALK) != 0u)) < refill_below) {
           const unsigned long long need = __ballot((fl & F_HAS) == 0u);
           if (chunk_next >= chunk_end) {
             uint32_t cbase = 0;
