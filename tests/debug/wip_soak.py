@@ -65,9 +65,10 @@ with pathtracer.Pathtracer(0) as pt:
             W, H = 40, 30
             src = host.make_sample_sources(W, H, info.seed + r)
             cam = host.default_camera(W, H)
-            for mode, nee in ((0, 0), (1, 1)):
+            # uber; per-material without light sampling; with it, in one kernel and in a kernel per material
+            for mode, nee, stage in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
                 prm = dict(max_bounces=4, seed=info.seed + r, shade_mode=mode, nee=nee)
-                pt.create_state(W, H, 900, src, pathtracer.default_params(**prm))
+                pt.create_state(W, H, 900, src, pathtracer.default_params(stage_kernels=stage, **prm))
                 pt.set_camera(cam)
                 pt.render_spp(2)
                 s4, cnt = pt.read_accum()
