@@ -429,16 +429,39 @@ def timed_render(pt, steps, warmup, spp_step, first_sample, before=None, after=N
     return elapsed, pt.stats(), extra
 
 
-def replay_counts(pt, ranges):
+REPLAY_STEPS = 4
+
+
+def replay_counts(pt, ranges, st):
     """Visit counts of the timed samples: the same sample numbers rendered again, untimed, with the counting
-    build of the traversal kernel."""
+    build of the traversal kernel.  `st` holds the timed run's statistics: a replay of every timed step must trace
+    exactly its rays.  With more than REPLAY_STEPS timed steps only the first REPLAY_STEPS are replayed (every step
+    renders the same number of samples of the same scene, so per-ray figures do not move) and the tallies are
+    scaled to the timed ray counts; the roofline block then says so (`counts_replayed_steps`)."""
     pt.stats_reset()
     pt.set_counting(True)
-    for first, n in ranges:
+    for first, n in ranges[:REPLAY_STEPS]:
         pt.set_sample_range(first)
         pt.render_spp(n)
     pt.set_counting(False)
-    return pt.stats()
+    cst = pt.stats()
+    if len(ranges) <= REPLAY_STEPS:
+        assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
+    else:
+        for counts, timed_rays, waves in ((cst.extend_counts, int(st.extend_rays), ("extend_tri_wave_lds", "extend_tri_wave_mem")),
+                                          (cst.connect_counts, int(st.connect_rays), ())):
+            if not counts.rays:
+                continue
+            k = timed_rays / counts.rays
+            assert abs(k * min(len(ranges), REPLAY_STEPS) / len(ranges) - 1.0) < 0.02, (k, len(ranges))
+            for name in ("rays", "tlas_nodes", "instance_visits", "blas_nodes", "triangles"):
+                setattr(counts, name, int(round(getattr(counts, name) * k)))
+            for name in waves:
+                setattr(cst, name, int(round(getattr(cst, name) * k)))
+        cst.shade_events = st.shade_events
+        cst.spawned_samples = st.spawned_samples
+    cst_steps = min(len(ranges), REPLAY_STEPS)
+    return cst, cst_steps
 
 
 def workload_name(args, W, H, geometry):
@@ -459,12 +482,12 @@ def secondary_line(args, local_rank):
         pt.set_camera(cam)
         steps, warmup, spp_step = 2, 1, args.spp_per_step
         elapsed, st, _ = timed_render(pt, steps, warmup, spp_step, 0)
-        cst = replay_counts(pt, [((warmup + k) * spp_step, spp_step) for k in range(steps)])
-        assert cst.extend_counts.rays == st.extend_rays
+        cst, cst_steps = replay_counts(pt, [((warmup + k) * spp_step, spp_step) for k in range(steps)], st)
         rays = int(st.extend_rays + st.connect_rays)
         roof = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, geometry), n_paths)
+        roof["counts_replayed_steps"] = cst_steps
     keep = ("bound", "kernel", "unit", "achieved", "peak", "frac", "frac_source", "fabric_frac", "hbm_frac", "traffic",
-            "traffic_note", "launch_ms", "launches", "per_ray")
+            "traffic_note", "launch_ms", "launches", "per_ray", "counts_replayed_steps")
     return {"metric": "Mrays/s (extend+shadow), dragon 1080p", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
             "config": {"workload": f"config{args.config}: {SCENES[args.config]} {W}x{H}, {info.max_bounces} bounces, "
@@ -509,10 +532,10 @@ def group_mode(args):
         per_member = [int(s.extend_rays + s.connect_rays) / elapsed / 1e6 for s in stats]
         # member 0 took the first spp_step sample numbers of every call
         m0 = grp.members[0]
-        cst = replay_counts(m0, [((args.warmup + k) * spp_step * n, spp_step) for k in range(args.steps)])
-        assert cst.extend_counts.rays == stats[0].extend_rays, (cst.extend_counts.rays, stats[0].extend_rays)
+        cst, cst_steps = replay_counts(m0, [((args.warmup + k) * spp_step * n, spp_step) for k in range(args.steps)], stats[0])
         roofline = extend_roofline(m0, stats[0], cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths,
                                    classic=bool(info.shade_mode))
+        roofline["counts_replayed_steps"] = cst_steps
         st = stats[0]
     out = result_line(args, info, W, H, n_paths, n, elapsed, rays, samples, reduce_s, st, roofline, None,
                       per_member, f"spp split x{n}, one process (mirt_group), peer-copy reduce to member 0")
@@ -638,10 +661,10 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: replay the timed samples with visit counting
-        cst = replay_counts(pt, [(first + (args.warmup + k) * spp_step, spp_step) for k in range(args.steps)])
-        assert cst.extend_counts.rays == st.extend_rays, (cst.extend_counts.rays, st.extend_rays)
+        cst, cst_steps = replay_counts(pt, [(first + (args.warmup + k) * spp_step, spp_step) for k in range(args.steps)], st)
         roofline = extend_roofline(pt, st, cst, elapsed, args, workload_name(args, W, H, args.geometry), n_paths,
                                    classic=bool(info.shade_mode))
+        roofline["counts_replayed_steps"] = cst_steps
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the host-core baseline belongs to the one-GPU line only
             cpu = cpu_baseline(arrays, info, W, H, src, cam, args.cpu_seconds)
