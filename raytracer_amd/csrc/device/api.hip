@@ -1099,13 +1099,14 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   int rc;
   auto &own = ctx->state_allocs;
   if ((rc = dev_alloc(ctx, own, &st.ray, threads)) != MIRT_OK) return rc;
-  if ((rc = dev_alloc(ctx, own, &st.hit, threads)) != MIRT_OK) return rc;
+
   if ((rc = dev_alloc(ctx, own, &st.path, threads)) != MIRT_OK) return rc;
-  // what only some shading paths touch is only allocated for them (52 of a slot's 184 bytes): the connect
-  // stage's records and queue with per-material shading and light sampling, the four material queues with one
-  // kernel per material on top of that
+  // what only some shading paths touch is only allocated for them (84 of a slot's 184 bytes): the connect
+  // stage's records (world-space hit, ShadowData) and queue with per-material shading and light sampling, the
+  // four material queues with one kernel per material on top of that
   const bool connect_stage = params->shade_mode == MIRT_SHADE_CLASSIC && params->nee != 0u;
   const bool material_queues = connect_stage && params->stage_kernels != 0u;
+  if ((rc = dev_alloc(ctx, own, &st.hit, connect_stage ? threads : 0u)) != MIRT_OK) return rc;
   if ((rc = dev_alloc(ctx, own, &st.shadow, connect_stage ? threads : 0u)) != MIRT_OK) return rc;
   for (int q = 0; q < Q_COUNT; ++q) {
     const bool used = q < Q_CONNECT || (q == Q_CONNECT ? connect_stage : material_queues);
@@ -1700,10 +1701,19 @@ int mirt_dump_extension_rays(mirt_ctx *ctx, MirtRay *out, size_t capacity, size_
   if (cnt > ctx->st.slots) return fail(ctx, MIRT_ERR_HIP, "dump: queue count exceeds slots");
   std::vector<uint32_t> idx(cnt);
   if (cnt) HIP_TRY(ctx, copy_sync(ctx->stream, idx.data(), ctx->st.qdata[Q_EXT0 + par], (size_t)cnt * 4, hipMemcpyDeviceToHost));
-  std::vector<MirtRay> all(ctx->st.slots);
-  HIP_TRY(ctx, copy_sync(ctx->stream, all.data(), ctx->st.ray, (size_t)ctx->st.slots * sizeof(MirtRay), hipMemcpyDeviceToHost));
+  // path-state rays keep position + last instance in their first quarter, direction + last triangle in the second
+  std::vector<uint32_t> all((size_t)8 * ctx->st.slots);
+  HIP_TRY(ctx, copy_sync(ctx->stream, all.data(), ctx->st.ray, (size_t)ctx->st.slots * sizeof(DRay), hipMemcpyDeviceToHost));
   size_t w = 0;
-  for (uint32_t k = 0; k < cnt && w < capacity; ++k) out[w++] = all[idx[k]];
+  for (uint32_t k = 0; k < cnt && w < capacity; ++k) {
+    const uint32_t *q = &all[(size_t)8 * idx[k]];
+    MirtRay r;
+    memcpy(r.pos, q, 12);
+    memcpy(r.dir, q + 4, 12);
+    r.last_inst = q[3];
+    r.last_prim = q[7];
+    out[w++] = r;
+  }
   *n_written = w;
   return MIRT_OK;
 } catch (...) {

@@ -25,10 +25,9 @@
 //
 // What a slot's records hold between the stages of a frame with light sampling
 // (DRay, DHit, DShadow of layout.h, as quarters of 16 bytes):
-//   after k_extend            hit[0] = u, v, triangle, instance (or kMissInst)
-//   after k_extend_finish     ray[0] = shadow-ray origin xyz, incoming direction x
-//                             ray[1] = incoming direction y z, then the hit's texture coordinate in scenes
-//                                      with textures (else the exclusion ids, no longer needed)
+//   after k_extend            ray[0] = u, v, triangle, instance (or kMissInst); ray[1] = incoming direction xyz, last triangle
+//   after k_extend_finish     ray[0] = shadow-ray origin xyz, texture coordinate u of the hit (scenes with textures)
+//                             ray[1] = incoming direction xyz, texture coordinate v (else the last triangle, no longer needed)
 //                             hit[0] = world position xyz, instance | front_face << 31
 //                             hit[1] = world normal xyz, b of the light sample
 //                             shadow[0] = direction to the light sample xyz, its probability (0: none shot)
@@ -71,15 +70,14 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
   }
   s.pb = path_q(st, slot, 1u);
   s.rng = load_rng(st, slot);
-  v3 rpos;
-  uint32_t li, lp;
-  load_ray(st.ray, slot, rpos, s.rdir, li, lp);
-  s.tu = __uint_as_float(li);  // !RAW: left there by k_extend_finish when the scene has textures
-  s.tv = __uint_as_float(lp);
-  const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
+  const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
+  const float4 ra = r4[0], rb = r4[1];
+  s.rdir = V3(rb.x, rb.y, rb.z);
+  s.tu = ra.w;  // !RAW: left in the ray's two exclusion words by k_extend_finish when the scene has textures
+  s.tv = rb.w;
   v3 hn;
   if (RAW) {
-    const float4 raw = h4[0];
+    const float4 raw = ra;  // the walk's result (load_pray in device_util.h)
     BestHit best;
     best.u = raw.x;
     best.v = raw.y;
@@ -91,6 +89,7 @@ __device__ __forceinline__ bool load_slot(const DScene &sc, const DState &st, ui
     s.hit_w = 0.0f;
     if (sc.tri_uv != nullptr) hit_uv(sc, best, s.tu, s.tv);
   } else {
+    const float4 *h4 = reinterpret_cast<const float4 *>(st.hit + slot);
     const float4 ha = h4[0], hb = h4[1];
     const uint32_t inst_ff = __float_as_uint(ha.w);
     s.inst = inst_ff & 0x7FFFFFFFu;
@@ -109,7 +108,7 @@ __device__ __forceinline__ void store_slot(const DState &st, uint32_t slot, cons
   path_q(st, slot, 1u) = s.pb;
   store_rng(st, slot, s.rng);
   // origins are offset instead of excluding the primitive just hit
-  store_ray(st.ray, slot, new_pos, new_dir, kNoPrim, kNoPrim);
+  store_pray(st.ray, slot, new_pos, new_dir, kNoPrim, kNoPrim);
 }
 
 __device__ __forceinline__ v3 rand_unit_sphere(float a, float b, float c) {
@@ -209,7 +208,8 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
     if (fin) {
       slot = ext[i];
       float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
-      const float4 raw = h4[0];
+      float4 *r4 = reinterpret_cast<float4 *>(st.ray + slot);
+      const float4 raw = r4[0];  // the walk's result
       BestHit best;
       best.u = raw.x;
       best.v = raw.y;
@@ -233,11 +233,10 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
         }
       } else {
         hit = true;
-        float4 *r4 = reinterpret_cast<float4 *>(st.ray + slot);
-        const float4 ra = r4[0], rb = r4[1];
+        const float4 rb = r4[1];
         v3 hp, hn;
         uint32_t ff;
-        finish_hit(sc, V3(ra.w, rb.x, rb.y), best, hp, hn, ff);
+        finish_hit(sc, V3(rb.x, rb.y, rb.z), best, hp, hn, ff);
         // archive/extension.slang:94-101: a hit costs one bounce; out of
         // bounces means terminate without shading
         uint32_t &pb = path_w(st, slot, 3u);
@@ -255,14 +254,12 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
           sh4[1] = make_float4(__uint_as_float(ls.inst), ls.dist, __uint_as_float(ls.prim), ls.a);
           h4[0] = make_float4(hp.x, hp.y, hp.z, __uint_as_float(best.inst | (ff << 31)));
           h4[1] = make_float4(hn.x, hn.y, hn.z, ls.b);
-          r4[0] = make_float4(ls.orig.x, ls.orig.y, ls.orig.z, ra.w);
-          if (sc.tri_uv != nullptr) {
-            // the material's texture coordinate rides in the ray's two exclusion words,
-            // which nothing reads between this kernel and the material's own store
-            float tu, tv;
-            hit_uv(sc, best, tu, tv);
-            r4[1] = make_float4(rb.x, rb.y, tu, tv);
-          }
+          // the material's texture coordinate rides in the ray's two exclusion words,
+          // which nothing reads between this kernel and the material's own store
+          float tu = 0.0f, tv = 0.0f;
+          if (sc.tri_uv != nullptr) hit_uv(sc, best, tu, tv);
+          r4[0] = make_float4(ls.orig.x, ls.orig.y, ls.orig.z, tu);
+          if (sc.tri_uv != nullptr) r4[1] = make_float4(rb.x, rb.y, rb.z, tv);
         }
       }
       if (RESPAWN && !hit && !have_end) {
@@ -578,7 +575,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
     uint32_t source = kNoSample;
     if (active) {
       slot = ext[i];
-      const uint32_t inst = __float_as_uint(reinterpret_cast<const float4 *>(st.hit + slot)[0].w);
+      const uint32_t inst = __float_as_uint(reinterpret_cast<const float4 *>(st.ray + slot)[0].w);  // the walk's result
       if (inst == kMissInst) {
         // rad += throughput * sky
         float4 pa = path_q(st, slot, 0u);

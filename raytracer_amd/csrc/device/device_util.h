@@ -151,6 +151,27 @@ __device__ __forceinline__ void store_ray(DRay *rays, uint32_t i, v3 pos, v3 dir
   r4[1] = make_float4(dir.y, dir.z, __uint_as_float(last_inst), __uint_as_float(last_prim));
 }
 
+// A slot's ray in the path state is laid out differently from the API's MirtRay: position and last instance in
+// the first quarter, direction and last triangle in the second —
+//   [px, py, pz, last_inst | dx, dy, dz, last_prim]
+// — so that the closest-hit walk, which is done with the first quarter once it has fetched the ray, leaves its
+// result there with one store (u, v, triangle, instance or kMissInst) and the kernel behind it reads result and
+// direction from ONE 32-byte record (there is no separate hit record on that path).
+__device__ __forceinline__ void load_pray(const DRay *rays, uint32_t i, v3 &pos, v3 &dir, uint32_t &last_inst,
+                                          uint32_t &last_prim) {
+  const float4 *r4 = reinterpret_cast<const float4 *>(rays + i);
+  const float4 a = r4[0], b = r4[1];
+  pos = V3(a.x, a.y, a.z);
+  last_inst = __float_as_uint(a.w);
+  dir = V3(b.x, b.y, b.z);
+  last_prim = __float_as_uint(b.w);
+}
+__device__ __forceinline__ void store_pray(DRay *rays, uint32_t i, v3 pos, v3 dir, uint32_t last_inst, uint32_t last_prim) {
+  float4 *r4 = reinterpret_cast<float4 *>(rays + i);
+  r4[0] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(last_inst));
+  r4[1] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(last_prim));
+}
+
 // Quarter k of a slot's path record (DPath: 0 = radiance + bounces, 1 = throughput + source, 2 = stream
 // state) and word w of the record (3 = bounces, 7 = source).  kPathPlanes lays the quarters out as three planes
 // of `slots` float4 each, so that a wave walking consecutive slots reads a contiguous kilobyte per load.

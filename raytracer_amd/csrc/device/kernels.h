@@ -44,8 +44,8 @@ enum StatId {
 constexpr uint32_t kSumStride = MIRT_SUM_STRIDE;
 
 struct DState {
-  DRay *ray;            // [slots]
-  DHit *hit;            // [slots]
+  DRay *ray;            // [slots] (position + last instance | direction + last triangle; the walk's result over the first half)
+  DHit *hit;            // [slots] (connect stage only)
   DPath *path;          // [slots]
   DShadow *shadow;      // [slots] (classic shading)
   uint32_t *qdata[Q_COUNT];  // [slots] each

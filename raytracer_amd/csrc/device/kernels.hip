@@ -310,10 +310,10 @@ __global__ __launch_bounds__(256) void k_spawn_first(DState st, DFrameParams fp)
 // ---------------------------------------------------------------- extend
 
 // The closest-hit walk of extensionMain (shaders/ray_extend.slang:12-33) for
-// every entry of this frame's extension queue.  It leaves the raw result in the
-// slot's hit record — u, v, the triangle id and the instance (kMissInst when
-// nothing was hit) in its first 16 bytes — for
-// the streaming kernel that follows; keeping the epilogue out of this kernel
+// every entry of this frame's extension queue.  It leaves the raw result — u, v, the
+// triangle id and the instance (kMissInst when nothing was hit) — in the first
+// quarter of the slot's ray record (load_pray in device_util.h), next to the
+// direction, for the streaming kernel that follows; keeping the epilogue out of this kernel
 // keeps its registers and instruction footprint small.
 
 // Diagnostic builds park every wave's own phase sums in the convergence flags (unused without adaptive
@@ -335,15 +335,16 @@ __global__ MIRT_ENGINE_BOUNDS void k_extend(DScene sc, DState st, DFrameParams f
   LaneCounts lc;
 
   auto fetch = [&](uint32_t slot, RayIn &r) {
-    load_ray(st.ray, slot, r.pos, r.dir, r.last_inst, r.last_prim);
+    load_pray(st.ray, slot, r.pos, r.dir, r.last_inst, r.last_prim);
     r.tmax = FLT_MAX;
     r.payload = slot;
   };
   auto finish = [&](bool fin, uint32_t slot, bool found, float t, const BestHit &best) {
     if (fin) {
-      float4 *h4 = reinterpret_cast<float4 *>(st.hit + slot);
+      // over the ray's first quarter (origin and last instance: the walk is done with them)
+      float4 *r4 = reinterpret_cast<float4 *>(st.ray + slot);
       (void)t;  // nothing downstream reads t: the hit point comes from the barycentrics
-      h4[0] = make_float4(best.u, best.v, __uint_as_float(best.prim), __uint_as_float(found ? best.inst : kMissInst));
+      r4[0] = make_float4(best.u, best.v, __uint_as_float(best.prim), __uint_as_float(found ? best.inst : kMissInst));
     }
   };
   trace_engine<false, COUNT>(sc, WorkSource{&st.qcount[W_EXTEND], count, ext, &st.stats[S_PHASE0], extend_phase_waves(st)}, lc, fetch, finish);
@@ -534,9 +535,8 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
     uint32_t source = kNoSample;
     if (active) {
       const float4 *r4 = reinterpret_cast<const float4 *>(st.ray + slot);
-      const float4 raw = reinterpret_cast<const float4 *>(st.hit + slot)[0];
       float4 pa = path_q(st, slot, 0u), pb = path_q(st, slot, 1u), pr = path_q(st, slot, 2u);
-      const float4 ra = r4[0], rb = r4[1];
+      const float4 raw = r4[0], rb = r4[1];  // the walk's result, the incoming direction
       BestHit best;
       best.u = raw.x;
       best.v = raw.y;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
         rad = pa;
         if (!RESPAWN) path_q(st, slot, 0u) = pa;
       } else {
-        const v3 wo = V3(ra.w, rb.x, rb.y);  // the incoming direction, not negated
+        const v3 wo = V3(rb.x, rb.y, rb.z);  // the incoming direction, not negated
         v3 hp, hn, wi;
         uint32_t ff;
         finish_hit(sc, wo, best, hp, hn, ff);
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
         }
         // ray.dir = wi; ray.pos = hit position, no epsilon: the primitive just hit is excluded
         // from the next traversal instead
-        if (alive) store_ray(st.ray, slot, hp, wi, best.inst, best.prim);
+        if (alive) store_pray(st.ray, slot, hp, wi, best.inst, best.prim);
       }
     }
     if (RESPAWN) {

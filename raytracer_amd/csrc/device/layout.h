@@ -116,14 +116,15 @@ static_assert(sizeof(DInst) == 128, "DInst must be 128 bytes");
 
 // Per-slot path state.  Records are 16-B multiples so a slot is read with
 // whole dwordx4 loads; slots are gathered through the queues' index lists.
-struct DRay {  // same bytes as MirtRay
+struct DRay {  // same bytes as MirtRay (the API's ray lists); the path state's own rays order the eight words
+               // differently, see load_pray in device_util.h
   float px, py, pz, dx;
   float dy, dz;
   uint32_t last_inst, last_prim;
 };
 static_assert(sizeof(DRay) == 32, "DRay must be 32 bytes");
 
-struct DHit {
+struct DHit {  // world-space hit of the connect stage (per-material shading with light sampling); not allocated otherwise
   float px, py, pz;
   uint32_t inst_ff;  // instance id | front_face << 31
   float nx, ny, nz;

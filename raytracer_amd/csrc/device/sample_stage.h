@@ -92,7 +92,7 @@ __device__ __forceinline__ void spawn_sample(const DState &st, const DFrameParam
   path_q(st, slot, 0u) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(fp.p.max_bounces));
   path_q(st, slot, 1u) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(source));
   store_rng(st, slot, rng);
-  store_ray(st.ray, slot, cb.pos, dir, kNoPrim, kNoPrim);
+  store_pray(st.ray, slot, cb.pos, dir, kNoPrim, kNoPrim);
 }
 
 }  // namespace mirt
