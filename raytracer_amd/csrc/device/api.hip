@@ -1101,7 +1101,7 @@ int mirt_state_create(mirt_ctx *ctx, uint32_t width, uint32_t height, uint32_t t
   if ((rc = dev_alloc(ctx, own, &st.ray, threads)) != MIRT_OK) return rc;
 
   if ((rc = dev_alloc(ctx, own, &st.path, threads)) != MIRT_OK) return rc;
-  // what only some shading paths touch is only allocated for them (84 of a slot's 184 bytes): the connect
+  // what only some shading paths touch is only allocated for them (84 of a slot's 180 bytes): the connect
   // stage's records (world-space hit, ShadowData) and queue with per-material shading and light sampling, the
   // four material queues with one kernel per material on top of that
   const bool connect_stage = params->shade_mode == MIRT_SHADE_CLASSIC && params->nee != 0u;

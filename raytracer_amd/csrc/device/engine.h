@@ -140,8 +140,8 @@ struct RayIn {
   uint32_t payload;  // the client's tag (slot or output index)
 };
 
-// Work distribution: every wave grabs chunks of kChunk consecutive queue
-// entries with one atomic per chunk and hands them to its lanes as they free up.
+// Work distribution: every wave reserves kChunk consecutive queue entries with one
+// atomic on the launch's cursor and hands them to its lanes as they free up.
 #ifndef MIRT_WORK_CHUNK
 #define MIRT_WORK_CHUNK 128u
 #endif
@@ -159,6 +159,13 @@ constexpr uint32_t kChunk = MIRT_WORK_CHUNK;
 #endif
 constexpr uint32_t kSmallChunk = MIRT_SMALL_CHUNK;
 constexpr int kSmallRefillBelow = MIRT_SMALL_REFILL_BELOW;
+// Launches that fill the grid fetch the rays of 64 entries at a time into registers, ahead of the lanes' need
+// (trace_engine's `stage`): a refill then waits for no memory.  Against fetching entry and ray at the refill:
+// k_extend -1.3 % on the knot, -2.5 % on the split suzanne, -6 % in the Cornell box (short rays: every service
+// point refills), -1 % per frame at 512 x 512.
+#ifndef MIRT_STAGE_RAYS
+#define MIRT_STAGE_RAYS 1
+#endif
 #ifndef MIRT_LONE_LEAF
 #define MIRT_LONE_LEAF 1
 #endif
@@ -320,6 +327,52 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   const int refill_below = small_launch ? kSmallRefillBelow : kRefillBelow;
   uint32_t chunk_next = 0, chunk_end = 0;
   bool exhausted = false;
+#if MIRT_STAGE_RAYS
+  // Launches that fill the grid stage their rays: a chunk's rays are fetched by the whole wave (lane l keeps ray l of
+  // the chunk in registers) and handed to the lanes that need one by cross-lane reads, and the three dependent round
+  // trips behind a ray — work cursor, queue entry, ray record — run one chunk apart: when a chunk's rays are asked
+  // for, the entries of the next one and the cursor of the one after it are asked for too, so nothing a refill waits
+  // for was requested less than a chunk ago.  (A wave holds up to 64 + 64 + 2 x kChunk entries that way, which a small
+  // launch cannot afford: those take the direct path below.)
+  const bool staged = !small_launch;
+  RayIn sray;
+  sray.pos = sray.dir = V3(0.0f, 0.0f, 0.0f);
+  sray.tmax = 0.0f;
+  sray.last_inst = sray.last_prim = sray.payload = 0u;
+  uint32_t st_next = 0, st_count = 0;  // the staged chunk: rays handed out, rays in it
+  uint32_t e_next = 0, n1_count = 0;   // the chunk behind it: its queue entries (one per lane), their number
+  uint32_t c_next = 0;                 // the cursor's answer for the reservation behind that (lane 0)
+  uint32_t res_base = 0, res_left = 0; // the reservation in use: its next chunk, chunks left in it
+  constexpr uint32_t kStageChunk = 64u;
+  // one cursor atomic reserves kChunk entries (it is one address for the whole GPU: at 64 entries each a scene
+  // of short rays waits for it)
+  constexpr uint32_t kStageReserve = kChunk > kStageChunk ? kChunk : kStageChunk;
+  auto chunk_entries = [&]() {  // asks for the entries of the next chunk
+    if (res_left == 0u) {
+      res_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_next);
+      res_left = kStageReserve / kStageChunk;
+      // past the end of the queue every later cursor is past it too: stop asking
+      if (res_base < ws.count && lane == 0u) c_next = atomicAdd(ws.counter, kStageReserve);
+    }
+    const uint32_t b = res_base < ws.count ? res_base : ws.count;
+    const uint32_t e = res_base + kStageChunk < ws.count ? res_base + kStageChunk : ws.count;
+    res_base += kStageChunk;
+    res_left--;
+    n1_count = e - b;
+    if (lane < n1_count) e_next = ws.entries != nullptr ? ws.entries[b + lane] : b + lane;
+  };
+  auto advance = [&]() {  // the staged chunk is used up: the next one moves in
+    st_next = 0u;
+    st_count = n1_count;
+    if (lane < st_count) fetch(e_next, sray);
+    if (n1_count != 0u) chunk_entries();
+  };
+  if (staged) {
+    if (lane == 0u) c_next = atomicAdd(ws.counter, kStageReserve);
+    chunk_entries();
+    exhausted = n1_count == 0u;
+  }
+#endif
 
   // per-lane walk state
   uint32_t fl = 0u;
@@ -722,19 +775,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
         }
         if ((fl & F_WALK) == 0u) fl = 0u;
         if (!exhausted && __popcll(__ballot((fl & F_WALK) != 0u)) < refill_below) {
-          const unsigned long long need = __ballot((fl & F_HAS) == 0u);
-          if (chunk_next >= chunk_end) {
-            uint32_t cbase = 0;
-            if (lane == 0u) cbase = atomicAdd(ws.counter, chunk);
-            cbase = (uint32_t)__shfl((int)cbase, 0);
-            chunk_next = cbase < ws.count ? cbase : ws.count;
-            chunk_end = cbase + chunk < ws.count ? cbase + chunk : ws.count;
-            if (chunk_next >= chunk_end) exhausted = true;
-          }
-          const uint32_t idx = chunk_next + trv_rank(need);
-          if ((fl & F_HAS) == 0u && idx < chunk_end) {
-            RayIn ray;
-            fetch(ws.entries != nullptr ? ws.entries[idx] : idx, ray);
+          auto install = [&](const RayIn &ray) {
             // a negative tmax marks an entry that traces nothing
             fl = (ray.tmax < 0.0f) ? F_HAS : (F_HAS | F_WALK);
             t = ray.tmax;
@@ -749,9 +790,55 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             nbase = tlas_nbase;
             tseed = 0.0f;
             leaf_count = 0u;
+          };
+#if MIRT_STAGE_RAYS
+          if (staged) {
+            // hand out staged rays; lanes left without one when the chunk runs out get theirs at the next service
+            // point (waiting here for the next chunk's rays costs more than their eight steps)
+            const unsigned long long need = __ballot((fl & F_HAS) == 0u);
+            if (st_next >= st_count && n1_count != 0u) advance();  // the wave's first refill
+            const uint32_t src = st_next + trv_rank(need);
+            RayIn ray;
+            {
+              const int a = (int)((src & 63u) << 2);
+              ray.pos.x = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.pos.x)));
+              ray.pos.y = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.pos.y)));
+              ray.pos.z = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.pos.z)));
+              ray.dir.x = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.dir.x)));
+              ray.dir.y = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.dir.y)));
+              ray.dir.z = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.dir.z)));
+              ray.tmax = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(sray.tmax)));
+              ray.last_inst = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)sray.last_inst);
+              ray.last_prim = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)sray.last_prim);
+              ray.payload = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)sray.payload);
+            }
+            if ((fl & F_HAS) == 0u && src < st_count) install(ray);
+            const uint32_t taken = (uint32_t)__popcll(need);
+            st_next = st_next + taken < st_count ? st_next + taken : st_count;
+            // a chunk that is used up is replaced at once, so that its rays arrive under the steps that follow
+            if (st_next >= st_count && n1_count != 0u) advance();
+            exhausted = st_next >= st_count && n1_count == 0u;
+          } else
+#endif
+          {
+            const unsigned long long need = __ballot((fl & F_HAS) == 0u);
+            if (chunk_next >= chunk_end) {
+              uint32_t cbase = 0;
+              if (lane == 0u) cbase = atomicAdd(ws.counter, chunk);
+              cbase = (uint32_t)__shfl((int)cbase, 0);
+              chunk_next = cbase < ws.count ? cbase : ws.count;
+              chunk_end = cbase + chunk < ws.count ? cbase + chunk : ws.count;
+              if (chunk_next >= chunk_end) exhausted = true;
+            }
+            const uint32_t idx = chunk_next + trv_rank(need);
+            if ((fl & F_HAS) == 0u && idx < chunk_end) {
+              RayIn ray;
+              fetch(ws.entries != nullptr ? ws.entries[idx] : idx, ray);
+              install(ray);
+            }
+            const uint32_t taken = (uint32_t)__popcll(need);
+            chunk_next = chunk_next + taken < chunk_end ? chunk_next + taken : chunk_end;
           }
-          const uint32_t taken = (uint32_t)__popcll(need);
-          chunk_next = chunk_next + taken < chunk_end ? chunk_next + taken : chunk_end;
         }
         if (exhausted && __ballot((fl & F_HAS) != 0u) == 0ull) break;
       }
@@ -819,7 +906,11 @@ __device__ __forceinline__ void finish_hit(const DScene &sc, v3 world_dir, const
                                            uint32_t &front_face) {
   const DInst *inst = &sc.inst[b.inst];
   const float4 *tri4 = reinterpret_cast<const float4 *>(sc.tri) + 3 * (size_t)(inst->tri_base + b.prim);
+#ifdef MIRT_PROBE_NRM_FROM_TRI  // timing probe only (wrong normals): what the second random 48-byte gather costs
+  const float4 *nrm4 = tri4;
+#else
   const float4 *nrm4 = reinterpret_cast<const float4 *>(sc.trin) + 3 * (size_t)(inst->tri_base + b.prim);
+#endif
   const float4 a0 = tri4[0], a1 = tri4[1], a2 = tri4[2];
   const float4 n0 = nrm4[0], n1 = nrm4[1], n2 = nrm4[2];
   const float u = b.u, v = b.v, w = 1.0f - u - v;
