@@ -166,6 +166,11 @@ constexpr int kSmallRefillBelow = MIRT_SMALL_REFILL_BELOW;
 #ifndef MIRT_STAGE_RAYS
 #define MIRT_STAGE_RAYS 1
 #endif
+#ifndef MIRT_STAGE_MIN_CHUNKS
+#define MIRT_STAGE_MIN_CHUNKS 16u  // launches of at least this many kChunk entries per wave of the grid are staged
+#endif
+constexpr bool kStageRays = MIRT_STAGE_RAYS != 0;
+constexpr uint32_t kStageMinChunks = MIRT_STAGE_MIN_CHUNKS;
 #ifndef MIRT_LONE_LEAF
 #define MIRT_LONE_LEAF 1
 #endif
@@ -306,35 +311,31 @@ __device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
 // one buffer descriptor; TLAS and BLAS nodes differ only in the lane's base and ray registers.
 // Everything a lane keeps per ray lives in registers; LDS holds the leaf cache and a
 // 64-entry list per wave.
-template <bool ANY, bool COUNT, class Fetch, class Finish>
-__device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource ws, LaneCounts &lc, Fetch fetch,
-                                             Finish finish) {
-  __shared__ uint32_t s_own[kEngineBlock / 64u][64];  // per wave: the lanes that wait with a small leaf, in lane order
-  __shared__ uint4 s_cache[kLeafCacheWords16 ? kLeafCacheWords16 : 1u];  // the scene's leaf-cache image (layout.h)
+//
+// STAGED selects how a wave comes by its rays (trace_engine picks by the launch's size): fetched 64 at a time
+// ahead of need, or entry and ray fetched when a lane asks.
+template <bool ANY, bool COUNT, bool STAGED, class Fetch, class Finish>
+__device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource ws, LaneCounts &lc, Fetch fetch,
+                                            Finish finish, uint32_t (&s_own)[kEngineBlock / 64u][64],
+                                            uint4 (&s_cache)[kLeafCacheWords16 ? kLeafCacheWords16 : 1u]) {
   const uint32_t tid = threadIdx.x;
-  if (kLeafCacheWords16 != 0u) {
-    const uint32_t n16 = sc.leaf_cache_bytes / 16u < kLeafCacheWords16 ? sc.leaf_cache_bytes / 16u : kLeafCacheWords16;
-    for (uint32_t i = tid; i < n16; i += kEngineBlock) s_cache[i] = sc.leaf_cache[i];
-    __syncthreads();
-  }
   const uint32_t lane = trv_lane();
   const BufferRsrc geo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(sc.geo), 0, (int)sc.geo_bytes, 0x00020000);
   const uint32_t tlas_nbase = sc.tlas_base * 32u;
 
   // wave-uniform work cursor; small launches take smaller chunks and refill later (kSmallChunk above)
-  const bool small_launch = ws.count < kChunk * (kEngineBlock / 64u) * gridDim.x;
+  const bool small_launch = !STAGED && ws.count < kChunk * (kEngineBlock / 64u) * gridDim.x;
   const uint32_t chunk = !small_launch ? kChunk : (kChunk < kSmallChunk ? kChunk : kSmallChunk);
   const int refill_below = small_launch ? kSmallRefillBelow : kRefillBelow;
   uint32_t chunk_next = 0, chunk_end = 0;
   bool exhausted = false;
-#if MIRT_STAGE_RAYS
-  // Launches that fill the grid stage their rays: a chunk's rays are fetched by the whole wave (lane l keeps ray l of
+  // Launches that fill the grid many times over stage their rays: a chunk's rays are fetched by the whole wave (lane l keeps ray l of
   // the chunk in registers) and handed to the lanes that need one by cross-lane reads, and the three dependent round
   // trips behind a ray — work cursor, queue entry, ray record — run one chunk apart: when a chunk's rays are asked
   // for, the entries of the next one and the cursor of the one after it are asked for too, so nothing a refill waits
-  // for was requested less than a chunk ago.  (A wave holds up to 64 + 64 + 2 x kChunk entries that way, which a small
-  // launch cannot afford: those take the direct path below.)
-  const bool staged = !small_launch;
+  // for was requested less than a chunk ago.  (A wave holds up to 64 + 64 + 2 x kChunk entries that way, which smaller
+  // launches cannot afford — with 512 entries per wave k_extend lost 11 % to it: those take the direct path below.)
+  constexpr bool staged = STAGED;
   RayIn sray;
   sray.pos = sray.dir = V3(0.0f, 0.0f, 0.0f);
   sray.tmax = 0.0f;
@@ -372,7 +373,6 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
     chunk_entries();
     exhausted = n1_count == 0u;
   }
-#endif
 
   // per-lane walk state
   uint32_t fl = 0u;
@@ -791,8 +791,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             tseed = 0.0f;
             leaf_count = 0u;
           };
-#if MIRT_STAGE_RAYS
-          if (staged) {
+          if constexpr (staged) {
             // hand out staged rays; lanes left without one when the chunk runs out get theirs at the next service
             // point (waiting here for the next chunk's rays costs more than their eight steps)
             const unsigned long long need = __ballot((fl & F_HAS) == 0u);
@@ -818,9 +817,7 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
             // a chunk that is used up is replaced at once, so that its rays arrive under the steps that follow
             if (st_next >= st_count && n1_count != 0u) advance();
             exhausted = st_next >= st_count && n1_count == 0u;
-          } else
-#endif
-          {
+          } else {
             const unsigned long long need = __ballot((fl & F_HAS) == 0u);
             if (chunk_next >= chunk_end) {
               uint32_t cbase = 0;
@@ -896,6 +893,23 @@ __device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource 
   }
   MIRT_PH_FLUSH(ws.phase);
   MIRT_PH_FLUSH_WAVE(ws.phase_waves);
+}
+
+// Fills the block's leaf cache and runs the engine in the form that suits the launch's size.
+template <bool ANY, bool COUNT, class Fetch, class Finish>
+__device__ __forceinline__ void trace_engine(const DScene &sc, const WorkSource ws, LaneCounts &lc, Fetch fetch,
+                                             Finish finish) {
+  __shared__ uint32_t s_own[kEngineBlock / 64u][64];  // per wave: the lanes that wait with a small leaf, in lane order
+  __shared__ uint4 s_cache[kLeafCacheWords16 ? kLeafCacheWords16 : 1u];  // the scene's leaf-cache image (layout.h)
+  if (kLeafCacheWords16 != 0u) {
+    const uint32_t n16 = sc.leaf_cache_bytes / 16u < kLeafCacheWords16 ? sc.leaf_cache_bytes / 16u : kLeafCacheWords16;
+    for (uint32_t i = threadIdx.x; i < n16; i += kEngineBlock) s_cache[i] = sc.leaf_cache[i];
+    __syncthreads();
+  }
+  if (kStageRays && ws.count >= kStageMinChunks * kChunk * (kEngineBlock / 64u) * gridDim.x)
+    engine_loop<ANY, COUNT, true>(sc, ws, lc, fetch, finish, s_own, s_cache);
+  else
+    engine_loop<ANY, COUNT, false>(sc, ws, lc, fetch, finish, s_own, s_cache);
 }
 
 // The record extensionMain stores for a hit (shaders/ray_extend.slang:86-89

@@ -523,6 +523,39 @@ def test_full_size_properties_per_material_path_1080p(pt, config_scenes):
     assert np.array_equal(a4[: 4 * 2048], w4) and np.array_equal(ac[:2048], wc)
 
 
+@pytest.mark.parametrize("cfg", [3, 5])
+def test_launches_that_stage_their_rays_match_the_oracle_slice(pt, config_scenes, cfg):
+    # The walk comes by its rays in two ways: launches of at least 16 x 128 entries per resident wave (8.4 M on
+    # 256 CUs) fetch them 64 at a time ahead of need, smaller ones when a lane asks.  With twelve slots per pixel
+    # at 1080p the first launches of both walks (closest hit, and shadow rays for configuration 5) are of the first
+    # kind; the same samples through one slot per pixel are of the second; both must be the oracle's.
+    arrays, info = config_scenes(cfg)
+    pt.upload_scene(arrays)
+    W, H, spp = 1920, 1080, 12
+    assert spp * W * H >= 2 * 16 * 128 * 16 * 256
+    kw = dict(max_bounces=info.max_bounces, seed=info.seed, shade_mode=info.shade_mode, nee=info.nee)
+    src = host.make_sample_sources(W, H, info.seed)
+    cam = host.default_camera(W, H)
+    prm = pathtracer.default_params(**kw)
+    pt.create_state(W, H, spp * W * H, src, prm)
+    pt.set_camera(cam)
+    pt.stats_reset()
+    pt.render_spp(spp)
+    a4, ac = pt.read_accum()
+    st = pt.stats()
+    assert np.all(ac == spp) and st.finished_samples == spp * W * H == st.spawned_samples
+    if info.nee:
+        assert st.connect_rays > 8400000
+    pt.create_state(W, H, W * H, src, prm)
+    pt.set_camera(cam)
+    pt.render_spp(spp)
+    b4, bc = pt.read_accum()
+    assert np.array_equal(a4, b4) and np.array_equal(ac, bc)
+    sc = po.Scene(arrays)
+    w4, wc, _ = sc.render(cam, src[:2048].copy(), W, H, po.default_params(**kw), 0, spp)
+    assert np.array_equal(a4[: 4 * 2048], w4) and np.array_equal(ac[:2048], wc)
+
+
 def test_full_size_properties_config4_thousand_instances_1080p(pt, config_scenes):
     # configuration 4 at full size (1000 instances of the full-size dragon stand-in, teapot,
     # suzanne and cube under one TLAS): ray-set parity on a sample, a slice of the render
