@@ -84,6 +84,28 @@ def test_closest_and_any_hit_ids_and_visit_counts(pt, config_scenes, small_knot_
     assert gac.as_dict() == wac.as_dict()
 
 
+def test_ray_lists_large_enough_to_be_staged(pt, config_scenes):
+    # ray lists of 16 x 128 entries per resident wave and more (8.4 M on 256 CUs) go through the form of the walk
+    # that fetches its rays 64 at a time ahead of need, with the list index as the queue entry: closest hits with
+    # visit counts and shadow queries against the oracle, on a list that does not end on a chunk
+    arrays, _ = config_scenes(1)
+    sc = po.Scene(arrays)
+    pt.upload_scene(arrays)
+    n = 2 * 16 * 128 * 16 * 256 // 2 + 64 * 100000 + 37
+    assert n > 8400000 * 1.5
+    rays = random_rays(n, 99, centre=(0.0, 0.0, 3.0), spread=2.0)
+    want, wc = sc.trace_closest(rays, True)
+    got, gc = pt.trace_closest(rays, True)
+    assert hits_equal(got, want)
+    assert gc.as_dict() == wc.as_dict()
+    assert (want["instance_id"] != ffi.NO_HIT).sum() > 100000
+    tmax = np.random.default_rng(4).uniform(0.2, 8.0, n).astype("<f4")
+    wany, wac = sc.trace_any(rays, tmax, True)
+    gany, gac = pt.trace_any(rays, tmax, True)
+    assert hits_equal(gany, wany)
+    assert gac.as_dict() == wac.as_dict()
+
+
 def test_empty_and_ragged_ray_sets(pt, config_scenes):
     arrays, _ = config_scenes(1)
     sc = po.Scene(arrays)
