@@ -284,6 +284,12 @@ __device__ __forceinline__ float4 geo_load16(BufferRsrc rsrc, uint32_t off) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// One word at a wave-uniform byte offset, read through the scalar cache: it comes back on the scalar counter, so
+// a wave does not wait for the vector fetches it has in flight (they return in order) before it may use it.
+__device__ __forceinline__ uint32_t geo_sload4(const unsigned char *geo, uint32_t uniform_off) {
+  typedef const __attribute__((address_space(4))) uint32_t *ConstWord;
+  return *(ConstWord)(geo + (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_off));
+}
 __device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
   return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
 }
@@ -447,7 +453,7 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
           const uint32_t ostart = bcast_u(leaf_start);
           const uint32_t otbase = bcast_u(tbase);
           uint32_t ocount = bcast_u(leaf_count);
-          if (ocount == kBigLeaf) ocount = geo_load4(geo, otbase + ostart * 48u + 12u);  // size stored out of line
+          if (ocount == kBigLeaf) ocount = geo_sload4(sc.geo, otbase + ostart * 48u + 12u);  // size stored out of line
           const uint32_t oskip = bcast_u(excl_prim);
           // per-lane best over triangles ostart + lane, + 64, ...
           // key: ANY -> index (first accepted in index order);
@@ -471,7 +477,7 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
             }
             return false;
           };
-          const uint32_t ocached = kLeafCacheWords16 != 0u ? geo_load4(geo, otbase + ostart * 48u + 44u) : 0u;
+          const uint32_t ocached = kLeafCacheWords16 != 0u ? geo_sload4(sc.geo, otbase + ostart * 48u + 44u) : 0u;
           if (ocached != 0u && kLeafCacheDirect) {
             // the leaf's scan blocks are in LDS: the same three planes as in memory
             const unsigned char *blk = reinterpret_cast<const unsigned char *>(s_cache) + (ocached - 1u) + lane * 16u;
@@ -497,7 +503,7 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
               if (consider(p, p0, sub3(p1, p0), sub3(p2, p0))) break;
             }
           } else {
-            uint32_t boff = geo_load4(geo, otbase + ostart * 48u + 28u) + lane * 16u;  // the leaf's scan blocks
+            uint32_t boff = geo_sload4(sc.geo, otbase + ostart * 48u + 28u) + lane * 16u;  // the leaf's scan blocks
             for (uint32_t k = lane; k < ocount; k += 64u, boff += kScanBlockBytes) {
               const uint32_t p = ostart + k;
               if (p == oskip) continue;
