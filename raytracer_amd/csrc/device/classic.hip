@@ -193,8 +193,6 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
   const int q0 = RESPAWN ? Q_EXT0 + (int)(par ^ 1u) : Q_TERM0 + (int)(par ^ 1u);
   __shared__ BlockPush2 sh;
   __shared__ BlockReserve shr;
-  CamBasis cb;
-  if (RESPAWN) cb = cam_basis(fp.cam);
   unsigned long long finished = 0, spawned = 0;
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
@@ -276,7 +274,7 @@ __global__ __launch_bounds__(kStreamBlock) void k_extend_finish(DScene sc, DStat
       }
       const unsigned long long si = block_reserve(shr, st.sample_index, done);
       if (done && si < fp.sample_limit) {
-        spawn_sample(st, fp, cb, slot, si);
+        spawn_sample(st, fp, cam_basis(fp.cam), slot, si);  // the basis is a few products, cheaper than registers held for it
         spawned++;
       } else if (done) {
         path_w(st, slot, 7u) = kNoSample;  // the slot retires
@@ -562,9 +560,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  CamBasis cb;
-  if (RESPAWN) cb = cam_basis(fp.cam);
-  unsigned long long shaded = 0, finished = 0, spawned = 0;
+  uint32_t shaded = 0, finished = 0, spawned = 0;  // of this thread: at most one per round of the loop
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
@@ -621,7 +617,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
       }
       const unsigned long long si = block_reserve(shr, st.sample_index, done);
       if (done && si < fp.sample_limit) {
-        spawn_sample(st, fp, cb, slot, si);
+        spawn_sample(st, fp, cam_basis(fp.cam), slot, si);  // the basis is a few products, cheaper than registers held for it
         spawned++;
         alive = true;
       } else if (done) {
@@ -642,9 +638,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
     }
   }
   if (lane_id() == 0u) {
-    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
-    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
-    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], (unsigned long long)finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], (unsigned long long)spawned);
   }
 }
 
@@ -663,9 +659,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_connect_s
   const uint32_t par = fp.frame & 1u;
   const uint32_t *cq = st.qdata[Q_CONNECT];
   const uint32_t count = st.qcount[Q_CONNECT];
-  CamBasis cb;
-  if (RESPAWN) cb = cam_basis(fp.cam);
-  unsigned long long shaded = 0, finished = 0, spawned = 0;
+  uint32_t shaded = 0, finished = 0, spawned = 0;  // of this thread: at most one per round of the loop
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
     const uint32_t i = base + threadIdx.x;
@@ -709,7 +703,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_connect_s
       }
       const unsigned long long si = block_reserve(shr, st.sample_index, done);
       if (done && si < fp.sample_limit) {
-        spawn_sample(st, fp, cb, slot, si);
+        spawn_sample(st, fp, cam_basis(fp.cam), slot, si);  // the basis is a few products, cheaper than registers held for it
         spawned++;
         alive = true;
       } else if (done) {
@@ -730,9 +724,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_connect_s
     }
   }
   if (lane_id() == 0u) {
-    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
-    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
-    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], (unsigned long long)finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], (unsigned long long)spawned);
   }
 }
 

@@ -515,9 +515,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
-  CamBasis cb;
-  if (RESPAWN) cb = cam_basis(fp.cam);
-  unsigned long long shaded = 0, finished = 0, spawned = 0;
+  uint32_t shaded = 0, finished = 0, spawned = 0;  // of this thread: at most one per round of the loop
   // Every access of this kernel is a miss of its own (slots are scattered over gigabytes of
   // path state), so what it waits for is round trips, not bytes: everything addressed by the
   // slot alone — the traversal's result, the path record, the ray — is requested at once, before
@@ -579,7 +577,7 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
       }
       const unsigned long long si = block_reserve(shr, st.sample_index, done);
       if (done && si < fp.sample_limit) {
-        spawn_sample(st, fp, cb, slot, si);
+        spawn_sample(st, fp, cam_basis(fp.cam), slot, si);  // the basis is a few products, cheaper than registers held for it
         spawned++;
         alive = true;
       } else if (done) {
@@ -600,9 +598,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
     }
   }
   if (lane_id() == 0u) {
-    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], shaded);
-    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], finished);
-    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], spawned);
+    if (shaded) atomicAdd(&st.stats[S_SHADE_EVENTS], (unsigned long long)shaded);
+    if (RESPAWN && finished) atomicAdd(&st.stats[S_FINISHED], (unsigned long long)finished);
+    if (RESPAWN && spawned) atomicAdd(&st.stats[S_SPAWNED], (unsigned long long)spawned);
   }
 }
 
