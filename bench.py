@@ -207,8 +207,8 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths, classic=False
     The walk is a per-lane chain of dependent small fetches and the scene sits in L2 +
     Infinity Cache, so the binding resource is the rate at which the memory pipeline serves
     per-lane gathers, not HBM streaming.
-      achieved  bytes the lanes actually request per launch (32 B per node visit, 48 B per
-                triangle fetched by a lane, 36 B per triangle of a whole-wave scan read from
+      achieved  bytes the lanes actually request per launch (32 B per node visit, 36 B per
+                triangle fetched by a lane or by a whole-wave scan read from
                 memory, 68 B per instance visit, 48 B per ray in and out) / the kernel's mean
                 launch time (HIP events on its stream)
       peak      32 B x the lane-steps/s of dependent 32-byte gathers from a table that fits an
@@ -225,7 +225,7 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths, classic=False
     nodes = c.tlas_nodes + c.blas_nodes
     tri_lds, tri_scan = int(cst.extend_tri_wave_lds), int(cst.extend_tri_wave_mem)
     tri_lane = int(c.triangles) - tri_lds - tri_scan
-    requested = 32 * nodes + 48 * tri_lane + 36 * tri_scan + 68 * c.instance_visits + 48 * c.rays
+    requested = 32 * nodes + 36 * tri_lane + 36 * tri_scan + 68 * c.instance_visits + 48 * c.rays
     scene_bytes, cache_bytes = pt.scene_bytes()
     gather_l2 = pt.bench_gather(2 << 20, 512, 3)     # lane-steps/s, table inside one XCD's L2
     gather_scene = pt.bench_gather(0, 512, 3)        # table = this scene's nodes + triangles, uniformly random
@@ -273,7 +273,7 @@ def extend_roofline(pt, st, cst, elapsed, args, workload, n_paths, classic=False
                                     f"scene_sized_table_{scene_bytes / 1e6:.0f}MB_uniform": gather_scene},
         "requested_bytes_per_launch": requested / launches,
         "lds_served_triangle_tests_per_launch": tri_lds / launches,
-        "lds_served_bytes_equivalent_per_launch": 48 * tri_lds / launches,
+        "lds_served_bytes_equivalent_per_launch": 36 * tri_lds / launches,
         "launch_ms": ext_s * 1e3, "launches": launches,
         "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note, "traffic_key": workload,
         "hbm_peak": HBM_PEAK_GBS,

@@ -171,6 +171,10 @@ constexpr int kSmallRefillBelow = MIRT_SMALL_REFILL_BELOW;
 #endif
 constexpr bool kStageRays = MIRT_STAGE_RAYS != 0;
 constexpr uint32_t kStageMinChunks = MIRT_STAGE_MIN_CHUNKS;
+#ifndef MIRT_TRI36
+#define MIRT_TRI36 1
+#endif
+constexpr bool kTri36 = MIRT_TRI36 != 0;  // lanes fetch their triangles from the packed 36-byte copy
 #ifndef MIRT_LONE_LEAF
 #define MIRT_LONE_LEAF 1
 #endif
@@ -289,6 +293,17 @@ __device__ __forceinline__ float4 geo_load16(BufferRsrc rsrc, uint32_t off) {
 __device__ __forceinline__ uint32_t geo_sload4(const unsigned char *geo, uint32_t uniform_off) {
   typedef const __attribute__((address_space(4))) uint32_t *ConstWord;
   return *(ConstWord)(geo + (uint32_t)__builtin_amdgcn_readfirstlane((int)uniform_off));
+}
+// A triangle of the packed copy (DScene::tri36_off): p0, e1, e2, twelve bytes each, as three 12-byte loads (16 + 16 + 4
+// bytes at the record's 4-byte alignment are slower than the 48-byte record's three aligned 16-byte loads).
+typedef uint32_t uint3v __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void geo_load_tri36(BufferRsrc rsrc, uint32_t off, v3 &p0, v3 &e1, v3 &e2) {
+  const uint3v a = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)off, 0, 0);
+  const uint3v b = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)off + 12, 0, 0);
+  const uint3v c = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)off + 24, 0, 0);
+  p0 = V3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+  e1 = V3(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+  e2 = V3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
 }
 __device__ __forceinline__ uint32_t geo_load4(BufferRsrc rsrc, uint32_t off) {
   return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
@@ -565,16 +580,24 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
           const v3 od = V3(rl_f(cdir.x), rl_f(cdir.y), rl_f(cdir.z));
           const float ot = rl_f(t);
           const uint32_t ostart = rl_u(leaf_start), ocount = rl_u(leaf_count), oskip = rl_u(excl_prim);
-          const uint32_t ofirst = rl_u(tbase) + __umul24(ostart, 48u);
+          const uint32_t ofirst = kTri36 ? sc.tri36_off + ((rl_u(tbase) - sc.tri_off) >> 2) * 3u + __umul24(ostart, 36u)
+                                         : rl_u(tbase) + __umul24(ostart, 48u);
           static_assert(kCoopLeaf <= 32u, "a small leaf fits the first two rows of sixteen lanes");
           unsigned long long key = ~0ull;
           float ku = 0.0f, kv = 0.0f, kt = 0.0f;
           if (lane < ocount && ostart + lane != oskip) {
-            const uint32_t toff = ofirst + __umul24(lane, 48u);
-            const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+            v3 p0, e1, e2;
+            if (kTri36) {
+              geo_load_tri36(geo, ofirst + __umul24(lane, 36u), p0, e1, e2);
+            } else {
+              const uint32_t toff = ofirst + __umul24(lane, 48u);
+              const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+              p0 = V3(a0.x, a0.y, a0.z);
+              e1 = V3(a1.x, a1.y, a1.z);
+              e2 = V3(a2.x, a2.y, a2.z);
+            }
             float t2, u, v;
-            if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
-                !(t2 > ot || t2 < 0.0f)) {
+            if (ray_tri_uvt(op, od, p0, e1, e2, t2, u, v) && !(t2 > ot || t2 < 0.0f)) {
               const uint32_t p = ostart + lane;
               key = ANY ? (unsigned long long)p
                         : (((unsigned long long)__float_as_uint(t2 + 0.0f) << 32) | (unsigned long long)(~p));
@@ -626,7 +649,9 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
           if (waits) own[rank] = lane;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          const uint32_t first_off = tbase + __umul24(leaf_start, 48u);  // byte offset of the leaf's first triangle
+          // byte offset of the leaf's first triangle
+          const uint32_t first_off = kTri36 ? sc.tri36_off + ((tbase - sc.tri_off) >> 2) * 3u + __umul24(leaf_start, 36u)
+                                            : tbase + __umul24(leaf_start, 48u);
           const uint32_t group = lane >> 2, quad = lane & 3u;
           for (uint32_t round = 0; round * 16u < n_wait; ++round) {
             const uint32_t r = round * 16u + group;
@@ -647,11 +672,18 @@ __device__ __forceinline__ void engine_loop(const DScene &sc, const WorkSource w
             float ku = 0.0f, kv = 0.0f, kt = 0.0f;
             for (uint32_t i = quad; __ballot(i < ocount) != 0ull; i += 4u) {
               if (i < ocount && ostart + i != oskip) {
-                const uint32_t toff = ofirst + __umul24(i, 48u);
-                const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+                v3 p0, e1, e2;
+                if (kTri36) {
+                  geo_load_tri36(geo, ofirst + __umul24(i, 36u), p0, e1, e2);
+                } else {
+                  const uint32_t toff = ofirst + __umul24(i, 48u);
+                  const float4 a0 = geo_load16(geo, toff), a1 = geo_load16(geo, toff + 16u), a2 = geo_load16(geo, toff + 32u);
+                  p0 = V3(a0.x, a0.y, a0.z);
+                  e1 = V3(a1.x, a1.y, a1.z);
+                  e2 = V3(a2.x, a2.y, a2.z);
+                }
                 float t2, u, v;
-                if (ray_tri_uvt(op, od, V3(a0.x, a0.y, a0.z), V3(a1.x, a1.y, a1.z), V3(a2.x, a2.y, a2.z), t2, u, v) &&
-                    !(t2 > ot || t2 < 0.0f)) {
+                if (ray_tri_uvt(op, od, p0, e1, e2, t2, u, v) && !(t2 > ot || t2 < 0.0f)) {
                   const uint32_t p = ostart + i;
                   const unsigned long long kk =
                       ANY ? (unsigned long long)p

@@ -176,6 +176,7 @@ static_assert(sizeof(DMaterial) == 64, "DMaterial must be 64 bytes");
 struct DScene {
   const unsigned char *geo;   // one allocation: the node array, then (at tri_off) the DTri array
   uint32_t geo_bytes, tri_off;
+  uint32_t tri36_off;         // the triangles again, 36 bytes each (p0, e1, e2 and nothing else), for the lanes' own fetches
   const DNode *nodes;         // = geo; every tree: node i of a tree at nodes[base + i]
   uint32_t tlas_base;         // base of the TLAS
   const uint32_t *tlas_big;   // out-of-line TLAS leaf sizes, indexed by the leaf's first slot
