@@ -560,6 +560,8 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
+  // with enough samples left for every entry, the next queue is this one copied in place (see k_finish_shade_uber)
+  const bool all_stay = RESPAWN && st.qcount[F_ALL_STAY] != 0u;
   uint32_t shaded = 0, finished = 0, spawned = 0;  // of this thread: at most one per round of the loop
   const uint32_t stride = gridDim.x * blockDim.x;
   for (uint32_t base = blockIdx.x * blockDim.x; base < count; base += stride) {  // uniform per block
@@ -623,13 +625,18 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_MATERIAL_WAVES) void k_finish_sh
       } else if (done) {
         path_w(st, slot, 7u) = kNoSample;  // the slot retires
       }
-      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
-                  false, slot);
+      if (all_stay) {
+        if (active) st.qdata[Q_EXT0 + (par ^ 1u)][i] = slot;
+      } else {
+        block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
+                    false, slot);
+      }
     } else {
       block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
                   &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
     }
   }
+  if (all_stay && blockIdx.x == 0u && threadIdx.x == 0u) st.qcount[Q_EXT0 + (par ^ 1u)] = count;
   for (int off = 32; off > 0; off >>= 1) {
     shaded += __shfl_down(shaded, off);
     if (RESPAWN) {

@@ -23,6 +23,9 @@ enum QueueId {
   // work cursors of the two ray-tracing kernels (chunks handed to waves), kept
   // in the same counter array and cleared by the sample kernel every frame
   W_EXTEND = Q_COUNT, W_CONNECT,
+  // set by the sample kernel of a frame: nonzero when the samples still to be handed out cover every entry
+  // of the frame's extension queue, i.e. no slot can retire in this frame (see k_finish_shade_uber)
+  F_ALL_STAY,
   QW_COUNT
 };
 

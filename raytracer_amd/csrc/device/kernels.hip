@@ -94,6 +94,11 @@ __global__ __launch_bounds__(kStreamBlock) void k_sample(DState st, DFrameParams
     st.qcount[Q_EMISSIVE] = 0u;
     st.qcount[W_EXTEND] = 0u;
     st.qcount[W_CONNECT] = 0u;
+    // With nothing on this frame's terminate queue no block of this kernel touches the sample counter or the
+    // extension queue, so both can be read here: when the samples still to be handed out cover every entry of the
+    // extension queue, no slot can retire in this frame.
+    st.qcount[F_ALL_STAY] =
+        (fp.respawn != 0u && count == 0u && *st.sample_index + st.qcount[Q_EXT0 + par] <= fp.sample_limit) ? 1u : 0u;
   }
 }
 
@@ -515,6 +520,9 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
   const uint32_t par = fp.frame & 1u;
   const uint32_t *ext = st.qdata[Q_EXT0 + par];
   const uint32_t count = st.qcount[Q_EXT0 + par];
+  // With enough samples left for every entry, each path that ends here is replaced and every entry stays: the next
+  // queue is this one, copied in place — no counting across the block, no atomic, none of their barriers.
+  const bool all_stay = RESPAWN && st.qcount[F_ALL_STAY] != 0u;
   uint32_t shaded = 0, finished = 0, spawned = 0;  // of this thread: at most one per round of the loop
   // Every access of this kernel is a miss of its own (slots are scattered over gigabytes of
   // path state), so what it waits for is round trips, not bytes: everything addressed by the
@@ -583,13 +591,18 @@ __global__ __launch_bounds__(kStreamBlock, MIRT_SHADE_WAVES) MIRT_SHADE_ATTR voi
       } else if (done) {
         path_w(st, slot, 7u) = kNoSample;  // the slot retires
       }
-      block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
-                  false, slot);
+      if (all_stay) {
+        if (active) st.qdata[Q_EXT0 + (par ^ 1u)][i] = slot;
+      } else {
+        block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive, nullptr, nullptr,
+                    false, slot);
+      }
     } else {
       block_push2(sh, &st.qcount[Q_EXT0 + (par ^ 1u)], st.qdata[Q_EXT0 + (par ^ 1u)], active && alive,
                   &st.qcount[Q_TERM0 + (par ^ 1u)], st.qdata[Q_TERM0 + (par ^ 1u)], active && !alive, slot);
     }
   }
+  if (all_stay && blockIdx.x == 0u && threadIdx.x == 0u) st.qcount[Q_EXT0 + (par ^ 1u)] = count;
   for (int off = 32; off > 0; off >>= 1) {
     shaded += __shfl_down(shaded, off);
     if (RESPAWN) {
